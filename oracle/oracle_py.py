@@ -1,0 +1,240 @@
+"""ctypes bindings for the CPU oracle (oracle/libpolar_oracle.so) and, when built, the real
+reference decoders (oracle/_ref/lib*.so).  TEST INFRASTRUCTURE ONLY: imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by polardecoding_amd/."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+CRC6_TAPS = [0, 5, 6]  # g(D) = D^6 + D^5 + 1 (CASCL_128.c:3, :212-214)
+CRC24C_TAPS = [0, 1, 2, 4, 8, 12, 13, 15, 17, 20, 21, 23, 24]  # CASCL_1024_L8.c:2-4, :253-265
+
+ALGO = {"SC": 0, "BP": 1, "SCL": 2, "CASCL": 3}
+
+
+def load_q(nmax=1024):
+    path = os.path.join(REPO, "polardecoding_amd", "data", "q5g_nmax1024.txt")
+    vals = []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("#"):
+                continue
+            vals += [int(x) for x in line.split()]
+    assert len(vals) == 1024
+    return vals
+
+
+def q_for(N):
+    return [x for x in load_q() if x < N]
+
+
+class _Code(C.Structure):
+    _fields_ = [("N", C.c_int), ("n", C.c_int), ("K", C.c_int), ("r", C.c_int), ("A", C.c_int),
+                ("ntaps", C.c_int), ("taps", C.c_int * 32),
+                ("info_order", C.POINTER(C.c_int)), ("frozen", C.POINTER(C.c_ubyte))]
+
+
+class _Sim(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("ranv", C.c_uint64), ("rani", C.c_int),
+                ("pn", C.c_int * 63), ("m", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "libpolar_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/libpolar_oracle.so missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = C.CDLL(path)
+        L.po_code_create.restype = C.POINTER(_Code)
+        L.po_code_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+        L.po_code_destroy.argtypes = [C.POINTER(_Code)]
+        dp = C.POINTER(C.c_double)
+        fp = C.POINTER(C.c_float)
+        ip = C.POINTER(C.c_int)
+        L.po_sc_decode_f64.argtypes = [C.POINTER(_Code), dp, ip]
+        L.po_bp_decode_f64.argtypes = [C.POINTER(_Code), dp, C.c_int, ip]
+        L.po_scl_decode_f64.argtypes = [C.POINTER(_Code), dp, C.c_int, C.c_int, ip, dp, ip]
+        L.po_sc_decode_f32.argtypes = [C.POINTER(_Code), fp, ip]
+        L.po_bp_decode_f32.argtypes = [C.POINTER(_Code), fp, C.c_int, ip]
+        L.po_scl_decode_f32.argtypes = [C.POINTER(_Code), fp, C.c_int, C.c_int, ip, fp, ip]
+        L.po_decode_batch_f64.argtypes = [C.POINTER(_Code), C.c_int, C.c_int, C.c_int, dp, C.c_size_t,
+                                          C.POINTER(C.c_uint32)]
+        L.po_sim_init.argtypes = [C.POINTER(_Sim), C.c_uint64]
+        L.po_sim_frame.argtypes = [C.POINTER(_Sim), C.POINTER(_Code), C.c_double, ip, dp]
+        L.po_sigma_from_db.restype = C.c_double
+        L.po_sigma_from_db.argtypes = [C.c_double]
+        L.po_llr_from_y.argtypes = [dp, C.c_double, dp, C.c_int]
+        L.po_run_sweep.argtypes = [C.POINTER(_Code), C.c_int, C.c_int, C.c_int, C.c_uint64, dp, C.c_int,
+                                   C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.po_count_bit_errors.argtypes = [C.POINTER(_Code), ip, ip]
+        _lib = L
+    return _lib
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Code:
+    """N, K, CRC taps -> frozen set in 5G reliability order (CASCL_1024_L8.c:209-217)."""
+
+    def __init__(self, N, K, crc_taps=None, Q=None):
+        self.N, self.K = N, K
+        self.taps = list(crc_taps) if crc_taps else []
+        self.r = max(self.taps) if self.taps else 0
+        q = np.asarray(Q if Q is not None else q_for(N), dtype=np.int32)
+        t = np.asarray(self.taps if self.taps else [0], dtype=np.int32)
+        self._h = lib().po_code_create(N, K, self.r, _ip(t), len(self.taps), _ip(q))
+        if not self._h:
+            raise ValueError("bad code parameters")
+        self.A = K + self.r
+        self.n = int(np.log2(N))
+        self.info_order = np.array([self._h.contents.info_order[i] for i in range(self.A)], dtype=np.int32)
+        self.frozen = np.ones(N, dtype=np.uint8)
+        self.frozen[self.info_order] = 0
+
+    def __del__(self):
+        try:
+            lib().po_code_destroy(self._h)
+        except Exception:
+            pass
+
+
+def sigma_from_db(db):
+    return lib().po_sigma_from_db(db)
+
+
+def llr_from_y(y, sigma):
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = np.empty_like(y)
+    lib().po_llr_from_y(_dp(y), sigma, _dp(out), y.size)
+    return out
+
+
+def decode(code, llr, algo, L=8, bp_iters=100, dtype="f64"):
+    """Decode one frame or a [B][N] batch.  Returns (u_hat [B][N] int32, pm [B], ties [B])."""
+    L_ = lib()
+    f32 = dtype == "f32"
+    llr = np.ascontiguousarray(llr, dtype=np.float32 if f32 else np.float64)
+    single = llr.ndim == 1
+    llr2 = llr.reshape(-1, code.N)
+    B = llr2.shape[0]
+    uh = np.zeros((B, code.N), dtype=np.int32)
+    pm = np.zeros(B, dtype=np.float32 if f32 else np.float64)
+    ties = np.zeros(B, dtype=np.int32)
+    rp = C.POINTER(C.c_float if f32 else C.c_double)
+    for b in range(B):
+        lp = llr2[b].ctypes.data_as(rp)
+        up = uh[b].ctypes.data_as(C.POINTER(C.c_int))
+        if algo == "SC":
+            rc = (L_.po_sc_decode_f32 if f32 else L_.po_sc_decode_f64)(code._h, lp, up)
+        elif algo == "BP":
+            rc = (L_.po_bp_decode_f32 if f32 else L_.po_bp_decode_f64)(code._h, lp, bp_iters, up)
+        else:
+            fn = L_.po_scl_decode_f32 if f32 else L_.po_scl_decode_f64
+            rc = fn(code._h, lp, L, 1 if algo == "CASCL" else 0, up,
+                    pm[b:].ctypes.data_as(rp), ties[b:].ctypes.data_as(C.POINTER(C.c_int)))
+        if rc != 0:
+            raise RuntimeError(f"oracle decode failed rc={rc}")
+    if single:
+        return uh[0], pm[0], ties[0]
+    return uh, pm, ties
+
+
+class Sim:
+    """The reference's transmit chain and RNG (SCL_1024.c:184-197, :238-261, :295-326)."""
+
+    def __init__(self, seed):
+        self._s = _Sim()
+        lib().po_sim_init(C.byref(self._s), seed)
+
+    def frame(self, code, sigma):
+        u = np.zeros(code.N, dtype=np.int32)
+        y = np.zeros(code.N, dtype=np.float64)
+        lib().po_sim_frame(C.byref(self._s), code._h, sigma, _ip(u), _dp(y))
+        return u, y
+
+    def frames(self, code, sigma, count):
+        us = np.zeros((count, code.N), dtype=np.int32)
+        ys = np.zeros((count, code.N), dtype=np.float64)
+        for i in range(count):
+            lib().po_sim_frame(C.byref(self._s), code._h, sigma, _ip(us[i]), _dp(ys[i]))
+        return us, ys
+
+    @property
+    def state(self):
+        return (int(self._s.ranv), int(self._s.rani), int(self._s.m))
+
+
+def run_sweep(code, algo, snr_db, ble, seed, L=8, bp_iters=100):
+    snr = np.asarray(snr_db, dtype=np.float64)
+    run = (C.c_long * len(snr))()
+    eb = (C.c_long * len(snr))()
+    rc = lib().po_run_sweep(code._h, ALGO[algo], L, bp_iters, seed, _dp(snr), len(snr), ble, run, eb)
+    if rc != 0:
+        raise RuntimeError(f"po_run_sweep rc={rc}")
+    return list(run), list(eb)
+
+
+def count_bit_errors(code, u, u_hat):
+    u = np.ascontiguousarray(u, dtype=np.int32)
+    u_hat = np.ascontiguousarray(u_hat, dtype=np.int32)
+    return lib().po_count_bit_errors(code._h, _ip(u), _ip(u_hat))
+
+
+# ---- the real reference, when oracle/_ref has been built (oracle/Makefile `ref`) -------------
+
+REF_PROGRAMS = {
+    # name: (N, K, crc taps, algo, L)
+    "SC_128": (128, 64, None, "SC", 1),
+    "SC_1024": (1024, 512, None, "SC", 1),
+    "BP_128": (128, 64, None, "BP", 1),
+    "BP_1024": (1024, 512, None, "BP", 1),
+    "SCL_128": (128, 64, None, "SCL", 8),
+    "SCL_1024": (1024, 512, None, "SCL", 8),
+    "CASCL_128": (128, 64, CRC6_TAPS, "CASCL", 8),
+    "CASCL_1024_L8": (1024, 512, CRC24C_TAPS, "CASCL", 8),
+}
+
+
+def ref_available(name):
+    return os.path.exists(os.path.join(HERE, "_ref", f"lib{name}.so"))
+
+
+class Ref:
+    """One compiled reference program (its decode function, unmodified)."""
+
+    def __init__(self, name):
+        path = os.path.join(HERE, "_ref", f"lib{name}.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle ref` where /root/reference exists")
+        self.name = name
+        self.l = C.CDLL(path)
+        self.l.ref_decode.argtypes = [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int)]
+        self.l.ref_last_pm.restype = C.c_double
+        self.l.ref_time_decode.restype = C.c_double
+        self.l.ref_time_decode.argtypes = [C.POINTER(C.c_double), C.c_double, C.c_long, C.POINTER(C.c_int)]
+        self.l.ref_init()
+        self.N = self.l.ref_block_length()
+
+    def decode(self, y, sigma):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        uh = np.zeros(self.N, dtype=np.int32)
+        self.l.ref_decode(_dp(y), sigma, _ip(uh))
+        return uh, self.l.ref_last_pm()
+
+    def time_decode(self, ys, sigma):
+        ys = np.ascontiguousarray(ys, dtype=np.float64)
+        uh = np.zeros(self.N, dtype=np.int32)
+        return self.l.ref_time_decode(_dp(ys), sigma, ys.shape[0], _ip(uh))

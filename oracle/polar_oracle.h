@@ -1,0 +1,102 @@
+/*
+ * polar_oracle.h -- CPU oracle for the polar-decode hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C, array-based restatement of the reference's per-frame decoders
+ * (CHEBSB/PolarDecoding: SCdecode / BP / SCLdecode / CASCL) and of the Monte-Carlo
+ * harness around them.  It exists to CHECK the HIP product path; only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  Nothing under
+ * polardecoding_amd/ links or calls it.
+ *
+ * Parity status: PINNED.  The restatement is validated (tests/test_oracle_*.py) against
+ *   (1) the reference C itself, compiled from /root/reference by oracle/Makefile into
+ *       oracle/_ref/ (bit-identical u_hat and path metric on seeded frames),
+ *   (2) golden vectors committed under tests/golden/ (generated from (1)),
+ *   (3) the reference's published fixed-seed run counts (myResult_*.zip logs).
+ *
+ * Every function cites the reference file:line it restates.
+ */
+#ifndef POLAR_ORACLE_H
+#define POLAR_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PO_MAX_TAPS 32
+#define PO_MAX_L 64
+
+typedef struct po_code {
+    int N, n;          /* block length, log2(N)                                  */
+    int K;             /* payload bits                                           */
+    int r;             /* CRC bits (0 = no CRC)                                  */
+    int A;             /* K + r unfrozen positions                               */
+    int ntaps;         /* number of exponents of g(D), including 0 and r         */
+    int taps[PO_MAX_TAPS];
+    int *info_order;   /* I[i], i < A: reliability order, I[i] = Q[N-A+i]        */
+    unsigned char *frozen; /* [N] 1 = frozen                                     */
+} po_code;
+
+/* Code construction (CASCL_1024_L8.c:209-217; SCL_1024.c:198-206).  Q = ascending-reliability
+ * sequence restricted to < N (length N).  taps may be NULL when r == 0. */
+po_code *po_code_create(int N, int K, int r, const int *taps, int ntaps, const int *Q);
+void po_code_destroy(po_code *c);
+
+/* 2*y/std/std (SCL_1024.c:576) */
+void po_llr_from_y(const double *y, double sigma, double *llr, int N);
+
+/* Decoders.  llr = channel LLRs [N]; u_hat = [N] ints 0/1 (frozen = 0).
+ * Return 0 on success. */
+int po_sc_decode_f64(const po_code *c, const double *llr, int *u_hat);            /* SC_128.c:395-460 */
+int po_bp_decode_f64(const po_code *c, const double *llr, int iters, int *u_hat); /* BP_1024.c:372-427 */
+/* crc != 0 -> CASCL selection rule (CASCL_1024_L8.c:725-755), else SCLdecode's arg-min (SCL_1024.c:667-678).
+ * pm_out (nullable) = metric of the chosen path; ties_out (nullable) = number of median-tie events. */
+int po_scl_decode_f64(const po_code *c, const double *llr, int L, int crc, int *u_hat,
+                      double *pm_out, int *ties_out);
+
+/* float32 arithmetic variants (same operation order; used to check the f32 kernels) */
+int po_sc_decode_f32(const po_code *c, const float *llr, int *u_hat);
+int po_bp_decode_f32(const po_code *c, const float *llr, int iters, int *u_hat);
+int po_scl_decode_f32(const po_code *c, const float *llr, int L, int crc, int *u_hat,
+                      float *pm_out, int *ties_out);
+
+/* Batched single-thread drivers (cpu_baseline leg): decode B frames back to back.
+ * algo: 0 SC, 1 BP, 2 SCL, 3 CASCL.  u_hat_bits: [B][N/32] packed (bit j of word j/32), nullable. */
+int po_decode_batch_f64(const po_code *c, int algo, int L, int bp_iters, const double *llr, size_t B,
+                        uint32_t *u_hat_bits);
+
+/* ---- Monte-Carlo harness (main() of every simulator; SCL_1024.c:136-292) ---- */
+typedef struct po_sim {
+    uint64_t seed, ranv;   /* Ranq1 state (SCL_1024.c:295-309) */
+    int rani;
+    int pn[63];            /* PN sequence (SCL_1024.c:185-197) */
+    int m;                 /* PN phase */
+} po_sim;
+
+void po_sim_init(po_sim *s, uint64_t seed);
+double po_sim_ranq1(po_sim *s);
+/* One frame of the transmit chain: fills u[N] (encoder input), y[N] (BPSK+AWGN). Advances RNG and PN phase. */
+void po_sim_frame(po_sim *s, const po_code *c, double sigma, int *u, double *y);
+/* Mismatches on the A unfrozen positions (CASCL_1024_L8.c:297-303). */
+int po_count_bit_errors(const po_code *c, const int *u, const int *u_hat);
+/* sigma = pow(10, dB/-20) (SCL_1024.c:226) */
+double po_sigma_from_db(double db);
+
+/* Full sequential sweep with the reference stop rule: for each SNR point run until `ble` block errors.
+ * algo as above.  run_out/errbit_out: per-point results.  Returns 0. */
+int po_run_sweep(const po_code *c, int algo, int L, int bp_iters, uint64_t seed,
+                 const double *snr_db, int n_snr, int ble, long *run_out, long *errbit_out);
+
+/* CRC helpers (CASCL_1024_L8.c:245-266 encode, :569-598 check) */
+void po_crc_encode(const po_code *c, const int *v /*K*/, int *w /*A*/);
+int po_crc_check(const po_code *c, const int *w /*A*/);
+
+/* Polar encode x = u * F^{(x)n}, natural order (SCL_1024.c:242-250 with Fn[i][j] = ((i&j)==j)) */
+void po_polar_encode(int N, const int *u, int *x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,164 @@
+/*
+ * ref_wrap.c -- builds ONE reference simulator (CHEBSB/PolarDecoding, e.g. CASCL_1024_L8.c) from its
+ * source WHERE IT LIES under /root/reference, unmodified, into oracle/_ref/ as a shared library and a
+ * small executable.  TEST INFRASTRUCTURE ONLY.  No reference text is copied into this repository: the
+ * source file is #included by path (-DREF_SRC="..."), with its main() renamed so that the real
+ * decode function (SCdecode / BP / SCLdecode / CASCL) can be called frame by frame.
+ *
+ *   -DREF_SRC="\"/root/reference/CASCL_1024_L8.c\""   the translation unit to wrap
+ *   -DREF_DECODE=CASCL                                  its decode entry point
+ *   -DREF_KIND=3                                        0 SC, 1 BP, 2 SCL, 3 CASCL
+ *
+ * What is restated here (because the reference keeps it inline in main(), SCL_1024.c:159-217) is
+ * only the graph/frozen-set SET-UP, done with the reference's own connectBCB() and Q table.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* time(NULL) seeds the CASCL and BP programs (CASCL_1024_L8.c:164): make it controllable. */
+static unsigned long long ref_time_value = 0;
+/* Fn is read from stdin (SCL_1024.c:207-217) and is not shipped: synthesise F^{(x)n} instead. */
+static long ref_scan_pos = 0;
+static int ref_scan_dim = 0;
+static int ref_scanf_int(int *dst)
+{
+    long i = ref_scan_pos / ref_scan_dim, j = ref_scan_pos % ref_scan_dim;
+    *dst = ((i & j) == j) ? 1 : 0;
+    ref_scan_pos++;
+    return 1;
+}
+#define time(x) ((time_t)ref_time_value)
+#define scanf(fmt, p) ref_scanf_int(p)
+#define main ref_main
+#include REF_SRC
+#undef main
+#undef scanf
+#undef time
+
+/* From here on N, K, n (and L, r for the list decoders) are the reference's macros and `std` its
+ * global noise deviation: no local identifier below may use those names. */
+
+enum { REF_BLOCK = N, REF_INFO = K, REF_LOG = n };
+#if REF_KIND >= 2
+enum { REF_LIST = L };
+#else
+enum { REF_LIST = 1 };
+#endif
+#if REF_KIND == 3
+enum { REF_CRC = r };
+#else
+enum { REF_CRC = 0 };
+#endif
+
+static int ref_ready = 0;
+
+int ref_block_length(void) { return REF_BLOCK; }
+int ref_info_bits(void) { return REF_INFO; }
+int ref_crc_bits(void) { return REF_CRC; }
+int ref_list_size(void) { return REF_LIST; }
+int ref_kind(void) { return REF_KIND; }
+
+/* Graph + information-set set-up of main() (SCL_1024.c:143-206), using the reference's globals and
+ * its connectBCB(); idempotent. */
+int ref_init(void)
+{
+    int a, b;
+    if (ref_ready) return 0;
+#if REF_KIND >= 2
+    PM = (double *)calloc(2 * REF_LIST, sizeof(double));
+    PMcand = (double *)calloc(2 * REF_LIST, sizeof(double));
+#endif
+    V = (node ***)calloc(REF_LOG + 1, sizeof(node **));
+    for (a = 0; a <= REF_LOG; a++) {
+        V[a] = (node **)calloc(REF_BLOCK, sizeof(node *));
+        for (b = 0; b < REF_BLOCK; b++) V[a][b] = (node *)calloc(1, sizeof(node));
+    }
+    for (a = 0; a <= REF_LOG; a++)
+        for (b = 0; b < REF_BLOCK; b++) initV[a][b] = 0;
+    for (b = 0; b < REF_BLOCK; b++) {
+        V[0][b]->pU = NULL;
+        V[0][b]->pL = NULL;
+        connectBCB(0, b);
+    }
+    for (a = 1; a < REF_LOG; a++)
+        for (b = 0; b < REF_BLOCK; b++) connectBCB(a, b);
+    for (b = 0; b < REF_BLOCK; b++) {
+        V[REF_LOG][b]->cU = NULL;
+        V[REF_LOG][b]->cL = NULL;
+    }
+    for (a = 0; a < REF_BLOCK; a++) inI[a] = 0;
+    for (a = 0; a < REF_INFO + REF_CRC; a++) {
+        I[a] = Q[REF_BLOCK - (REF_INFO + REF_CRC) + a];
+        inI[I[a]] = 1;
+    }
+    ref_ready = 1;
+    return 0;
+}
+
+/* One call of the reference decoder: y = channel observations, sigma -> global `std`. */
+int ref_decode(const double *y, double sigma, int *u_hat)
+{
+    if (!ref_ready) ref_init();
+    std = sigma;
+    REF_DECODE((double *)y, u_hat);
+    return 0;
+}
+
+/* Path metric of the path the list decoders just chose (same selection rule as the decoder). */
+double ref_last_pm(void)
+{
+#if REF_KIND == 2
+    int a, best = 0;
+    for (a = 1; a < REF_LIST; a++)
+        if (PM[a] < PM[best]) best = a;
+    return PM[best];
+#elif REF_KIND == 3
+    int a, best = -1;
+    for (a = 0; a < REF_LIST; a++)
+        if (CRcheck(a) && (best < 0 || PM[a] < PM[best])) best = a;
+    if (best < 0) {
+        best = 0;
+        for (a = 1; a < REF_LIST; a++)
+            if (PM[a] < PM[best]) best = a;
+    }
+    return PM[best];
+#else
+    return 0.0;
+#endif
+}
+
+/* Decode `count` frames back to back and return the seconds spent inside the decoder only
+ * (cpu_baseline, kind "reference").  y: [count][N]. */
+double ref_time_decode(const double *y, double sigma, long count, int *u_hat_last)
+{
+    struct timespec t0, t1;
+    long f;
+    if (!ref_ready) ref_init();
+    std = sigma;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (f = 0; f < count; f++) REF_DECODE((double *)(y + f * (long)REF_BLOCK), u_hat_last);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* Run the reference's own main() untouched (its SNR sweep, stop rule and printf lines). */
+int ref_run_main(unsigned long long seed_time)
+{
+    ref_time_value = seed_time;
+    ref_scan_pos = 0;
+    ref_scan_dim = REF_BLOCK;
+    setvbuf(stdout, NULL, _IOLBF, 0);
+    return ref_main();
+}
+
+#ifdef REF_BUILD_EXE
+int main(int argc, char **argv)
+{
+    unsigned long long seed = 0;
+    if (argc > 1) seed = strtoull(argv[1], NULL, 10);
+    return ref_run_main(seed);
+}
+#endif
