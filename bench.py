@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: decoded frames/s of CRC-aided SCL, N=1024 K=512 CRC-24C L=8.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the decode hot path (one kernel launch through the C ABI,
+polar_decode_device) over one batch of synthetic BPSK-AWGN frames per GPU, inputs (channel LLRs)
+already resident in HBM.  Frames are independent, so the batch shards across ranks with no
+data-path collective (weak scaling: 2^17 frames per GPU per step = BASELINE config 4's 2^20 over
+8 GPUs); RCCL is used only for the final block/bit error counters and the max-over-ranks time.
+
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel, HIP-event
+timed on its stream) and `cpu_baseline` (the real reference C, oracle/_ref, one thread, bounded
+sample).  The CPU oracle / reference is imported ONLY for that baseline leg.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import polardecoding_amd as pa  # noqa: E402
+
+N, K = 1024, 512
+CRC = pa.CRC24C_TAPS
+R = max(CRC)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def polar_transform_(x):
+    """x: [B, N] uint8 on device; in-place x = u * F^{(x)n}, natural order (SCL_1024.c:242-250)."""
+    B, n_ = x.shape
+    s = 1
+    while s < n_:
+        v = x.view(B, n_ // (2 * s), 2, s)
+        v[:, :, 0, :] ^= v[:, :, 1, :]
+        s *= 2
+    return x
+
+
+def make_batch(B, snr_db, info_order, device, gen, dtype=torch.float64):
+    """Synthetic frames of the reference's transmit chain shape: random payload -> CRC multiply by g(D)
+    (CASCL_1024_L8.c:245-266) -> u[I[i]] = w[i] -> polar encode -> BPSK + AWGN -> LLR = 2y/s/s."""
+    v = torch.randint(0, 2, (B, K), device=device, dtype=torch.uint8, generator=gen)
+    w = torch.zeros((B, K + R), device=device, dtype=torch.uint8)
+    for t in CRC:
+        w[:, t:t + K] ^= v
+    u = torch.zeros((B, N), device=device, dtype=torch.uint8)
+    u[:, info_order] = w
+    x = polar_transform_(u.clone())
+    sigma = 10.0 ** (-snr_db / 20.0)  # R = 1/2 (CASCL_1024_L8.c:237)
+    noise = torch.randn((B, N), device=device, dtype=torch.float64, generator=gen)
+    y = (1.0 - 2.0 * x.to(torch.float64)) + sigma * noise
+    llr = (2.0 * y / sigma / sigma).to(dtype).contiguous()
+    # pack u into words for the device error counter
+    ub = u.view(B, N // 32, 32).to(torch.int64)
+    weights = (1 << torch.arange(32, device=device, dtype=torch.int64))
+    words = (ub * weights).sum(-1)
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+    return llr, words
+
+
+def cpu_baseline(snr_db, seconds_target=15.0):
+    """The reference's CASCL() itself (oracle/_ref/libCASCL_1024_L8.so, built from /root/reference by
+    oracle/Makefile), one thread, decode call only, on frames of the same distribution."""
+    try:
+        from oracle import oracle_py as O
+    except Exception as e:  # pragma: no cover
+        return {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"oracle unavailable: {e}"}
+    code = O.Code(N, K, O.CRC24C_TAPS)
+    sig = O.sigma_from_db(snr_db)
+    sim = O.Sim(1024)
+    if O.ref_available("CASCL_1024_L8"):
+        ref = O.Ref("CASCL_1024_L8")
+        nfr = 256
+        us, ys = sim.frames(code, sig, nfr)
+        t = ref.time_decode(ys[:32], sig)  # probe
+        rate = 32 / t
+        reps = max(1, int(seconds_target * rate / nfr))
+        tot = 0.0
+        for _ in range(reps):
+            tot += ref.time_decode(ys, sig)
+        return {"value": reps * nfr / tot, "unit": "frames/s", "cores": 1, "kind": "reference",
+                "sample": f"{reps * nfr} frames @ {snr_db} dB, CASCL() of CASCL_1024_L8.c compiled gcc -O2, decode call only"}
+    nfr = 512
+    us, ys = sim.frames(code, sig, nfr)
+    llr = np.stack([O.llr_from_y(y, sig) for y in ys])
+    t0 = time.perf_counter()
+    cnt = 0
+    while time.perf_counter() - t0 < seconds_target:
+        O.lib().po_decode_batch_f64(code._h, 3, 8, 0, llr.ctypes.data_as(O.C.POINTER(O.C.c_double)), nfr, None)
+        cnt += nfr
+    return {"value": cnt / (time.perf_counter() - t0), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{cnt} frames @ {snr_db} dB, build's C restatement (oracle/polar_oracle.c), single thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1 << 17, help="frames per GPU per step")
+    ap.add_argument("--snr", type=float, default=2.0)
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    dtype = pa.F64 if args.dtype == "f64" else pa.F32
+    dec = pa.CASCL(N, K, L=8, crc_taps=CRC, dtype=dtype, device=local)
+    dec.use_torch_stream()
+    info = torch.tensor(pa.q_sequence(N)[N - (K + R):], device=device, dtype=torch.long)
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(20261004 + rank)
+    B = args.batch
+    in_dtype = torch.float64 if args.dtype == "f64" else torch.float32
+    batches = [make_batch(B, args.snr, info, device, gen, in_dtype) for _ in range(2)]
+    out_bits = torch.empty((B, N // 32), dtype=torch.int32, device=device)
+    counters = torch.zeros(2, dtype=torch.int64, device=device)
+
+    def step(i):
+        llr, _ = batches[i & 1]
+        dec.decode_device(llr, out_bits=out_bits)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    # FER of the last step (outside the timed region): device compare + RCCL sum of two counters
+    dec.count_errors_device(out_bits, batches[(args.steps - 1) & 1][1], counters)
+    torch.cuda.synchronize()
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+    blk, bits = [int(v) for v in counters.tolist()]
+
+    # dominant-kernel timing with HIP events on the kernel's own stream (rank 0's GPU)
+    reps = max(3, min(10, args.steps))
+    ms_kernel = dec.time_decode_device(batches[0][0], out_bits, reps)
+    in_bytes = 8 if args.dtype == "f64" else 4
+    alg_bytes = B * (N * in_bytes + N // 8)  # LLRs in, packed bits out
+    achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9
+
+    if rank == 0:
+        total_frames = world * B * args.steps
+        value = total_frames / elapsed
+        out = {
+            "metric": "decoded frames/sec, N=1024 K=512 CA-SCL L=8",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"CASCL_1024_L8: N=1024 K=512 CRC-24C L=8, {B} frames/GPU/step "
+                                   f"(2^20 over 8 GPUs), BPSK-AWGN Eb/N0={args.snr} dB, LLRs resident in HBM",
+                       "frames_per_gpu_per_step": B, "snr_db": args.snr, "parallelism": f"frames sharded x{world}"},
+            "fer": {"block_errors": blk, "bit_errors": bits, "frames": world * B,
+                    "fer": blk / float(world * B)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": dec.kernel_name, "kernel_ms": ms_kernel,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "path is VALU/LDS-bound, not HBM-bound (SURVEY.md 0.5); see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.snr)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

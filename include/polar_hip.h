@@ -1,0 +1,134 @@
+/*
+ * polar_hip.h -- C ABI of libpolar_hip.so: MI355X-native (gfx950) polar decoders.
+ *
+ * Drop-in boundary for the per-frame decode functions of CHEBSB/PolarDecoding.  The reference has no
+ * plugin/FFI layer; its boundary is a C function symbol plus file-scope globals:
+ *
+ *     void SCdecode (double *y, int *u_hat);   SC_128.c:78, :395     (N,K,n #define; std, inI[] global)
+ *     void BP       (double *y, int *u_hat);   BP_1024.c:114, :372   (+ iterMax)
+ *     void SCLdecode(double *y, int *u_hat);   SCL_1024.c:134, :547  (+ L; PM, PMcand, surviv global)
+ *     void CASCL    (double *y, int *u_hat);   CASCL_1024_L8.c:141, :601 (+ r, CRC taps inline)
+ *
+ * Every entry point below names the reference interface it replaces.  Plain pointers and sizes only;
+ * no C++ or torch types.  All functions return 0 on success or a negative POLAR_E* code; nothing is
+ * printed (the reference's printf diagnostics "Oops!" / "Wrong propagation order!" / "Error!",
+ * SCL_1024.c:418, :622, :651, become the per-frame flags word).
+ *
+ * Thread-safety: a polar_ctx is bound to one GPU and one HIP stream and is not re-entrant (neither is
+ * the reference: all its scratch is global).  Use one ctx per host thread / per GPU.
+ */
+#ifndef POLAR_HIP_H
+#define POLAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* algo */
+#define POLAR_ALGO_SC 0    /* SCdecode   SC_128.c:395-460                      */
+#define POLAR_ALGO_BP 1    /* BP         BP_1024.c:372-427                     */
+#define POLAR_ALGO_SCL 2   /* SCLdecode  SCL_1024.c:547-680                    */
+#define POLAR_ALGO_CASCL 3 /* CASCL      CASCL_1024_L8.c:601-761               */
+
+/* dtype: the arithmetic type the message passing runs in */
+#define POLAR_F64 0 /* IEEE binary64 like the reference: bit-identical decisions (the parity gate) */
+#define POLAR_F32 1 /* binary32: same operation order, FER-equivalent, not bit-identical           */
+
+/* error codes */
+#define POLAR_OK 0
+#define POLAR_EINVAL (-1)   /* bad argument / unsupported configuration        */
+#define POLAR_ENOMEM (-2)   /* host or device allocation failed                */
+#define POLAR_EDEVICE (-3)  /* HIP runtime error (see polar_last_error)        */
+#define POLAR_ENOKERNEL (-4)/* no kernel instantiation for this (N, L, dtype)  */
+
+/* per-frame flags word */
+#define POLAR_FLAG_TIE 0x1u      /* a median tie occurred (reference prints "Oops!", SCL_1024.c:621-622) */
+#define POLAR_FLAG_CRC_PASS 0x2u /* CASCL: the chosen path passed the CRC (CASCL_1024_L8.c:738-746)       */
+
+typedef struct polar_ctx polar_ctx;
+
+/* Replaces the reference's compile-time configuration (#define N K n L r iterMax, CASCL_1024_L8.c:16-21;
+ * the Q-table derived I[] / inI[], :209-217; the CRC taps written inline at :253-265 and :581-593). */
+typedef struct polar_cfg {
+    int N;                 /* block length, power of two, 32..4096                                       */
+    int K;                 /* payload bits                                                               */
+    int crc_r;             /* CRC length r (0 = none)                                                    */
+    const int *crc_taps;   /* exponents of g(D) incl. 0 and r, e.g. {0,5,6} (CASCL_128.c:212-214)        */
+    int n_taps;
+    int L;                 /* list size, power of two 1..32 (SC: 1)                                      */
+    int algo;              /* POLAR_ALGO_*                                                               */
+    int bp_iters;          /* BP round trips (reference: iterMax = 100, BP_1024.c:16)                    */
+    const int *info_order; /* I[0..K+crc_r): unfrozen positions in reliability order (I[i] = Q[N-(K+r)+i]).
+                              NULL -> built from the 5G sequence like the reference does.                 */
+    int dtype;             /* POLAR_F64 | POLAR_F32                                                      */
+    int device;            /* HIP device ordinal                                                         */
+} polar_cfg;
+
+int polar_create(const polar_cfg *cfg, polar_ctx **out);
+void polar_destroy(polar_ctx *ctx);
+const char *polar_strerror(int code);
+/* text of the last HIP error seen by this ctx ("" if none) */
+const char *polar_last_error(const polar_ctx *ctx);
+
+/* --- reference-shaped single-frame call -------------------------------------------------------------
+ * Identical result to  std = sigma; X(y, u_hat);  for X = SCdecode / BP / SCLdecode / CASCL
+ * (SCL_1024.c:263: the per-frame call in main()).  y: N channel observations (not LLRs: the LLR
+ * 2*y/std/std is formed inside, SCL_1024.c:574-578).  u_hat: N ints, fully overwritten, frozen = 0. */
+int polar_decode(polar_ctx *ctx, const double *y, double sigma, int *u_hat);
+
+/* --- north-star call shape: decode(llr_in, frozen_mask, N, L) ----------------------------------------
+ * One frame of channel LLRs and a frozen mask (1 = frozen; the reference's !inI[], SCL_1024.c:198-206).
+ * Plain SCL (L > 1) or SC (L == 1) in f64.  Contexts are cached per (N, L, mask). */
+int polar_decode_llr(const double *llr_in, const unsigned char *frozen_mask, int N, int L, int *u_hat);
+
+/* --- batched, host buffers ---------------------------------------------------------------------------
+ * B frames.  llr_in [B][N] row-major channel LLRs (double).  frozen_mask: NULL (use cfg) or [N] override
+ * for SC/BP/SCL (CASCL needs cfg's info_order for the CRC).  u_hat [B][N] ints 0/1.
+ * pm_out (nullable) [B]: metric of the chosen path (SCL/CASCL; 0 otherwise).  flags (nullable) [B]. */
+int polar_decode_batch(polar_ctx *ctx, const double *llr_in, const unsigned char *frozen_mask, size_t B,
+                       int *u_hat, double *pm_out, unsigned *flags);
+
+/* Same, but the input is channel observations y and the kernel forms 2*y/sigma/sigma on load
+ * (SCL_1024.c:576, operation order kept). */
+int polar_decode_batch_y(polar_ctx *ctx, const double *y, double sigma, size_t B, int *u_hat,
+                         double *pm_out, unsigned *flags);
+
+/* --- batched, device buffers (the measured path; asynchronous on the ctx stream) ---------------------
+ * d_in: [B][N] of double (in_is_f32 = 0) or float (in_is_f32 = 1), LLRs, or y when sigma > 0.
+ * d_uhat_bits: [B][N/32] uint32, bit (j & 31) of word j >> 5 = u_hat[j].
+ * d_pm (nullable): [B] double.  d_flags (nullable): [B] uint32. */
+int polar_decode_device(polar_ctx *ctx, const void *d_in, int in_is_f32, double sigma, size_t B,
+                        uint32_t *d_uhat_bits, double *d_pm, uint32_t *d_flags);
+
+/* --- error accounting on device (main()'s compare loop, CASCL_1024_L8.c:296-305) ---------------------
+ * d_u_bits: [B][N/32] transmitted u.  Adds to d_counters[0] (block errors) and d_counters[1] (bit errors on
+ * the K + r unfrozen positions).  d_frame_err (nullable): [B] uint32 bit errors per frame (needed to cut at
+ * the reference's sequential stop rule). */
+int polar_count_errors_device(polar_ctx *ctx, const uint32_t *d_uhat_bits, const uint32_t *d_u_bits, size_t B,
+                              unsigned long long *d_counters, uint32_t *d_frame_err);
+
+/* stream plumbing: the ctx owns a stream by default; a host framework may hand in its own
+ * (hipStream_t passed as void*). */
+int polar_set_stream(polar_ctx *ctx, void *hip_stream);
+void *polar_get_stream(polar_ctx *ctx);
+int polar_synchronize(polar_ctx *ctx);
+
+/* Time `reps` launches of the decode kernel on B resident frames with HIP events on the ctx stream
+ * (bench.py's roofline leg).  Returns average milliseconds per launch in *ms_per_launch. */
+int polar_time_decode_device(polar_ctx *ctx, const void *d_in, int in_is_f32, double sigma, size_t B,
+                             uint32_t *d_uhat_bits, int reps, float *ms_per_launch);
+
+/* introspection */
+int polar_ctx_info(const polar_ctx *ctx, int *N, int *K, int *A, int *L, int *algo, int *dtype);
+/* name of the kernel instantiation this ctx launches (for matching rocprofv3 output) */
+const char *polar_kernel_name(const polar_ctx *ctx);
+/* library build id string */
+const char *polar_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

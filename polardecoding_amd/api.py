@@ -1,0 +1,255 @@
+"""ctypes binding of libpolar_hip.so and the host-side mirror of the reference decode functions.
+
+Reference call shape (SCL_1024.c:134, :263, :547):  ``void SCLdecode(double *y, int *u_hat)`` with
+``N, K, n, L`` as #defines and ``std``, ``inI[]`` as globals.  Here the #defines/globals become the
+constructor arguments of a decoder object and the call keeps its two data arguments::
+
+    dec = SCLdecode(N=1024, K=512, L=8)       # SCL_1024.c:13-16
+    u_hat = dec(y, sigma)                     # == std = sigma; SCLdecode(y, u_hat)
+
+No CPU fallback exists: a missing library raises PolarError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ALGO_SC, ALGO_BP, ALGO_SCL, ALGO_CASCL = 0, 1, 2, 3
+F64, F32 = 0, 1
+FLAG_TIE, FLAG_CRC_PASS = 1, 2
+CRC6_TAPS = (0, 5, 6)  # g(D) = D^6 + D^5 + 1 (CASCL_128.c:3)
+CRC24C_TAPS = (0, 1, 2, 4, 8, 12, 13, 15, 17, 20, 21, 23, 24)  # CASCL_1024_L8.c:2-4
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class PolarError(RuntimeError):
+    pass
+
+
+class _Cfg(C.Structure):
+    _fields_ = [("N", C.c_int), ("K", C.c_int), ("crc_r", C.c_int), ("crc_taps", C.POINTER(C.c_int)),
+                ("n_taps", C.c_int), ("L", C.c_int), ("algo", C.c_int), ("bp_iters", C.c_int),
+                ("info_order", C.POINTER(C.c_int)), ("dtype", C.c_int), ("device", C.c_int)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libpolar_hip.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Load libpolar_hip.so (built by __graft_entry__.build()).  Raises if absent: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise PolarError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(path)
+    vp, dp, ip, up = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_uint)
+    L.polar_create.argtypes = [C.POINTER(_Cfg), C.POINTER(vp)]
+    L.polar_destroy.argtypes = [vp]
+    L.polar_strerror.restype = C.c_char_p
+    L.polar_strerror.argtypes = [C.c_int]
+    L.polar_last_error.restype = C.c_char_p
+    L.polar_last_error.argtypes = [vp]
+    L.polar_decode.argtypes = [vp, dp, C.c_double, ip]
+    L.polar_decode_llr.argtypes = [dp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, ip]
+    L.polar_decode_batch.argtypes = [vp, dp, C.POINTER(C.c_ubyte), C.c_size_t, ip, dp, up]
+    L.polar_decode_batch_y.argtypes = [vp, dp, C.c_double, C.c_size_t, ip, dp, up]
+    L.polar_decode_device.argtypes = [vp, vp, C.c_int, C.c_double, C.c_size_t, vp, vp, vp]
+    L.polar_count_errors_device.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
+    L.polar_set_stream.argtypes = [vp, vp]
+    L.polar_get_stream.restype = vp
+    L.polar_get_stream.argtypes = [vp]
+    L.polar_synchronize.argtypes = [vp]
+    L.polar_time_decode_device.argtypes = [vp, vp, C.c_int, C.c_double, C.c_size_t, vp, C.c_int,
+                                           C.POINTER(C.c_float)]
+    L.polar_ctx_info.argtypes = [vp, ip, ip, ip, ip, ip, ip]
+    L.polar_kernel_name.restype = C.c_char_p
+    L.polar_kernel_name.argtypes = [vp]
+    L.polar_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def q_sequence(N):
+    """5G reliability order restricted to < N (what the reference hard-codes, SC_1024.c:42-91)."""
+    vals = []
+    with open(os.path.join(_HERE, "data", "q5g_nmax1024.txt")) as f:
+        for line in f:
+            if not line.startswith("#"):
+                vals += [int(x) for x in line.split()]
+    return [x for x in vals if x < N]
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+class Decoder:
+    """One polar_ctx: a (N, K, CRC, L, algo, dtype) configuration bound to one GPU."""
+
+    def __init__(self, N, K, algo, L=1, crc_taps=None, bp_iters=100, dtype=F64, device=0, info_order=None):
+        self._h = C.c_void_p()
+        self._lib = load_library()
+        self.N, self.K, self.algo, self.dtype, self.device = N, K, algo, dtype, device
+        taps = np.asarray(list(crc_taps) if crc_taps else [0], dtype=np.int32)
+        cfg = _Cfg()
+        cfg.N, cfg.K = N, K
+        cfg.crc_r = int(max(taps)) if crc_taps else 0
+        cfg.crc_taps = _ptr(taps, C.c_int)
+        cfg.n_taps = len(taps) if crc_taps else 0
+        cfg.L, cfg.algo, cfg.bp_iters, cfg.dtype, cfg.device = L, algo, bp_iters, dtype, device
+        io = None
+        if info_order is not None:
+            io = np.ascontiguousarray(info_order, dtype=np.int32)
+            cfg.info_order = _ptr(io, C.c_int)
+        rc = self._lib.polar_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise PolarError(f"polar_create: {self._lib.polar_strerror(rc).decode()} (rc={rc})")
+        A, Lr = C.c_int(), C.c_int()
+        self._lib.polar_ctx_info(self._h, None, None, C.byref(A), C.byref(Lr), None, None)
+        self.A, self.L = A.value, Lr.value
+        self.NW = N // 32
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.polar_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.polar_strerror(rc).decode()
+            det = self._lib.polar_last_error(self._h).decode()
+            raise PolarError(f"{what}: {msg} {det} (rc={rc})")
+
+    @property
+    def kernel_name(self):
+        return self._lib.polar_kernel_name(self._h).decode()
+
+    # ---- host buffers -------------------------------------------------------------------------------
+    def __call__(self, y, sigma):
+        """Reference call shape: channel observations y[N] and sigma (the global ``std``) -> u_hat[N]."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.shape != (self.N,):
+            raise ValueError(f"y must have shape ({self.N},)")
+        uh = np.empty(self.N, dtype=np.int32)
+        self._check(self._lib.polar_decode(self._h, _ptr(y, C.c_double), float(sigma), _ptr(uh, C.c_int)),
+                    "polar_decode")
+        return uh
+
+    def decode_batch(self, llr, frozen_mask=None, want_pm=True):
+        llr = np.ascontiguousarray(llr, dtype=np.float64).reshape(-1, self.N)
+        B = llr.shape[0]
+        uh = np.empty((B, self.N), dtype=np.int32)
+        pm = np.zeros(B, dtype=np.float64)
+        fl = np.zeros(B, dtype=np.uint32)
+        fm = None
+        if frozen_mask is not None:
+            fm = np.ascontiguousarray(frozen_mask, dtype=np.uint8)
+        self._check(self._lib.polar_decode_batch(self._h, _ptr(llr, C.c_double),
+                                                 _ptr(fm, C.c_ubyte) if fm is not None else None, B,
+                                                 _ptr(uh, C.c_int), _ptr(pm, C.c_double), _ptr(fl, C.c_uint)),
+                    "polar_decode_batch")
+        return uh, pm, fl
+
+    def decode_batch_y(self, y, sigma):
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1, self.N)
+        B = y.shape[0]
+        uh = np.empty((B, self.N), dtype=np.int32)
+        pm = np.zeros(B, dtype=np.float64)
+        fl = np.zeros(B, dtype=np.uint32)
+        self._check(self._lib.polar_decode_batch_y(self._h, _ptr(y, C.c_double), float(sigma), B,
+                                                   _ptr(uh, C.c_int), _ptr(pm, C.c_double), _ptr(fl, C.c_uint)),
+                    "polar_decode_batch_y")
+        return uh, pm, fl
+
+    # ---- device buffers (torch tensors on this ctx's GPU) ---------------------------------------------
+    def use_torch_stream(self):
+        """Run on torch's current stream so that torch ops and decodes are ordered."""
+        import torch
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._lib.polar_set_stream(self._h, C.c_void_p(s)), "polar_set_stream")
+
+    def decode_device(self, d_in, sigma=0.0, out_bits=None, pm=None, flags=None):
+        """d_in: torch CUDA tensor [B][N] float64 or float32 (LLRs, or y if sigma > 0).
+        Returns out_bits: int32 tensor [B][N/32] (bit j&31 of word j>>5 = u_hat[j])."""
+        import torch
+        assert d_in.is_cuda and d_in.is_contiguous() and d_in.shape[-1] == self.N
+        B = d_in.numel() // self.N
+        if out_bits is None:
+            out_bits = torch.empty((B, self.NW), dtype=torch.int32, device=d_in.device)
+        f32 = 1 if d_in.dtype == torch.float32 else 0
+        if not f32 and d_in.dtype != torch.float64:
+            raise ValueError("input must be float64 or float32")
+        self._check(self._lib.polar_decode_device(
+            self._h, C.c_void_p(d_in.data_ptr()), f32, float(sigma), B, C.c_void_p(out_bits.data_ptr()),
+            C.c_void_p(pm.data_ptr()) if pm is not None else None,
+            C.c_void_p(flags.data_ptr()) if flags is not None else None), "polar_decode_device")
+        return out_bits
+
+    def count_errors_device(self, uhat_bits, u_bits, counters, frame_err=None):
+        B = uhat_bits.shape[0]
+        self._check(self._lib.polar_count_errors_device(
+            self._h, C.c_void_p(uhat_bits.data_ptr()), C.c_void_p(u_bits.data_ptr()), B,
+            C.c_void_p(counters.data_ptr()),
+            C.c_void_p(frame_err.data_ptr()) if frame_err is not None else None), "polar_count_errors_device")
+
+    def time_decode_device(self, d_in, out_bits, reps, sigma=0.0):
+        import torch
+        B = d_in.numel() // self.N
+        ms = C.c_float()
+        self._check(self._lib.polar_time_decode_device(
+            self._h, C.c_void_p(d_in.data_ptr()), 1 if d_in.dtype == torch.float32 else 0, float(sigma), B,
+            C.c_void_p(out_bits.data_ptr()), int(reps), C.byref(ms)), "polar_time_decode_device")
+        return ms.value
+
+    def synchronize(self):
+        self._check(self._lib.polar_synchronize(self._h), "polar_synchronize")
+
+
+# ---- mirrors of the reference entry points (same names, same argument meaning) -----------------------
+
+def SCdecode(N, K, **kw):
+    """SC_128.c:395 / SC_1024.c:434 -- ``SCdecode(y, u_hat)``."""
+    return Decoder(N, K, ALGO_SC, L=1, **kw)
+
+
+def BP(N, K, iterMax=100, **kw):
+    """BP_1024.c:372 -- ``BP(y, u_hat)``; iterMax is BP_1024.c:16."""
+    return Decoder(N, K, ALGO_BP, L=1, bp_iters=iterMax, **kw)
+
+
+def SCLdecode(N, K, L=8, **kw):
+    """SCL_1024.c:547 -- ``SCLdecode(y, u_hat)``; L is SCL_1024.c:16."""
+    return Decoder(N, K, ALGO_SCL, L=L, **kw)
+
+
+def CASCL(N, K, L=8, crc_taps=CRC24C_TAPS, **kw):
+    """CASCL_1024_L8.c:601 -- ``CASCL(y, u_hat)``; r and g(D) are CASCL_1024_L8.c:2-4, :19."""
+    return Decoder(N, K, ALGO_CASCL, L=L, crc_taps=crc_taps, **kw)
+
+
+def decode(llr_in, frozen_mask, N, L):
+    """BASELINE.json north_star call shape ``decode(llr_in, frozen_mask, N, L)`` -> u_hat[N]."""
+    lib = load_library()
+    llr = np.ascontiguousarray(llr_in, dtype=np.float64)
+    fm = np.ascontiguousarray(frozen_mask, dtype=np.uint8)
+    if llr.shape != (N,) or fm.shape != (N,):
+        raise ValueError("llr_in and frozen_mask must have shape (N,)")
+    uh = np.empty(N, dtype=np.int32)
+    rc = lib.polar_decode_llr(_ptr(llr, C.c_double), _ptr(fm, C.c_ubyte), N, L, _ptr(uh, C.c_int))
+    if rc != 0:
+        raise PolarError(f"polar_decode_llr: {lib.polar_strerror(rc).decode()} (rc={rc})")
+    return uh

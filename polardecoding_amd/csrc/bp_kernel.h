@@ -1,0 +1,151 @@
+// bp_kernel.h -- flooding belief-propagation decoder (reference: BP, BP_1024.c:372-427).
+//
+// One codeword per workgroup; one butterfly (two CHK) per thread and stage; all messages in LDS.
+// The reference keeps l[0..n][N] and r[0..n][N].  Of those only l[1..n-1] and r[1..n-1] are ever
+// re-read: l[n] is the channel LLR (constant), r[0] is the frozen prior 999/0 (BP_1024.c:386-391,
+// taken from the mask), r[n] is written but never read, and l[0] is read only by the final hard
+// decision (:417-425).  Dropping the dead rows leaves (2(n-1)+1) N reals = 152 KB for N = 1024 in
+// f64, which is what lets a whole f64 codeword sit in one CU's 160 KB LDS.
+// Stage order, operand order inside CHK and inside the sums are the reference's.
+#pragma once
+#include "polar_math.h"
+
+namespace polar {
+
+struct BpParams {
+    const void *in;          // [B][N] double or float (LLR, or y when sigma > 0)
+    double sigma;
+    uint32_t *out_bits;      // [B][N/32]
+    const uint32_t *frozen;  // [N/32]
+    int N, n, B, iters;
+};
+
+template <typename R, typename IN>
+__global__ __launch_bounds__(512) void k_bp(BpParams P)
+{
+    const int N = P.N, n = P.n, NW = N >> 5;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    R *ch = reinterpret_cast<R *>(smem);
+    R *lm = ch + N;                       // rows 1..n-1 of l
+    R *rm = lm + (size_t)(n - 1) * N;     // rows 1..n-1 of r
+    uint32_t *obits = reinterpret_cast<uint32_t *>(rm + (size_t)(n - 1) * N);  // [NW]
+
+    for (int frame = blockIdx.x; frame < P.B; frame += gridDim.x) {
+        const IN *src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
+        for (int i = tid; i < N; i += nt) {
+            double v = (double)src[i];
+            if (P.sigma > 0) v = llr_from_y(v, P.sigma);
+            ch[i] = (R)v;  // BP_1024.c:381-382
+        }
+        for (int i = tid; i < (n - 1) * N; i += nt) {
+            lm[i] = R(0);  // BP_1024.c:378-380
+            rm[i] = R(0);  // BP_1024.c:384-386
+        }
+        for (int i = tid; i < NW; i += nt) obits[i] = 0;
+        __syncthreads();
+
+        for (int it = 0; it < P.iters; ++it) {
+            const bool last = (it + 1 == P.iters);
+            // R sweep (BP_1024.c:395-404); stage n-1 only produces r[n], which nobody reads
+            for (int i = 0; i + 1 < n; ++i) {
+                const int s = 1 << i;
+                for (int b = tid; b < N / 2; b += nt) {
+                    const int j = ((b >> i) << (i + 1)) | (b & (s - 1));
+                    R r0, r1;
+                    if (i == 0) {
+                        r0 = ((P.frozen[j >> 5] >> (j & 31)) & 1) ? R(999) : R(0);
+                        r1 = ((P.frozen[(j + s) >> 5] >> ((j + s) & 31)) & 1) ? R(999) : R(0);
+                    } else {
+                        r0 = rm[(size_t)(i - 1) * N + j];
+                        r1 = rm[(size_t)(i - 1) * N + j + s];
+                    }
+                    const R *lrow = (i + 1 == n) ? ch : lm + (size_t)i * N;
+                    const R l0 = lrow[j], l1 = lrow[j + s];
+                    const R a = chk<R>(r0, l1 + r1);
+                    const R c = r1 + chk<R>(r0, l0);
+                    rm[(size_t)i * N + j] = a;
+                    rm[(size_t)i * N + j + s] = c;
+                }
+                __syncthreads();
+            }
+            // L sweep (BP_1024.c:406-415); l[0] is needed only for the final decision
+            for (int i = n - 1; i >= (last ? 0 : 1); --i) {
+                const int s = 1 << i;
+                for (int b = tid; b < N / 2; b += nt) {
+                    const int j = ((b >> i) << (i + 1)) | (b & (s - 1));
+                    R r0, r1;
+                    bool f0 = false, f1 = false;
+                    if (i == 0) {
+                        f0 = (P.frozen[j >> 5] >> (j & 31)) & 1;
+                        f1 = (P.frozen[(j + s) >> 5] >> ((j + s) & 31)) & 1;
+                        r0 = f0 ? R(999) : R(0);
+                        r1 = f1 ? R(999) : R(0);
+                    } else {
+                        r0 = rm[(size_t)(i - 1) * N + j];
+                        r1 = rm[(size_t)(i - 1) * N + j + s];
+                    }
+                    const R *lrow = (i + 1 == n) ? ch : lm + (size_t)i * N;
+                    const R l0 = lrow[j], l1 = lrow[j + s];
+                    const R a = chk<R>(l0, l1 + r1);
+                    const R c = l1 + chk<R>(r0, l0);
+                    if (i > 0) {
+                        lm[(size_t)(i - 1) * N + j] = a;
+                        lm[(size_t)(i - 1) * N + j + s] = c;
+                    } else {
+                        // BP_1024.c:417-425: frozen -> 0, else (l + r >= 0) -> 0
+                        const uint32_t b0 = (!f0 && !(a + r0 >= R(0))) ? 1u : 0u;
+                        const uint32_t b1 = (!f1 && !(c + r1 >= R(0))) ? 1u : 0u;
+                        if (b0) atomicOr(&obits[j >> 5], 1u << (j & 31));
+                        if (b1) atomicOr(&obits[(j + s) >> 5], 1u << ((j + s) & 31));
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < NW; i += nt) P.out_bits[(size_t)frame * NW + i] = obits[i];
+        __syncthreads();
+    }
+}
+
+template <typename R>
+constexpr size_t bp_lds_bytes(int N, int n)
+{
+    return sizeof(R) * (size_t)N * (1 + 2 * (n - 1)) + sizeof(uint32_t) * (size_t)(N / 32);
+}
+
+// ---- error accounting (main()'s compare loop, CASCL_1024_L8.c:296-305) -------------------------------
+// One thread per frame word would be enough; one wave per frame keeps it trivially coalesced.
+struct CountParams {
+    const uint32_t *uhat;    // [B][NW]
+    const uint32_t *u;       // [B][NW]
+    const uint32_t *info;    // [NW] 1 = unfrozen position
+    unsigned long long *counters;  // [2] block errors, bit errors
+    uint32_t *frame_err;     // [B] or null
+    int NW, B;
+};
+
+__global__ __launch_bounds__(256) void k_count_errors(CountParams P)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    unsigned long long blk = 0, bits = 0;
+    for (int f = wave; f < P.B; f += nwaves) {
+        int e = 0;
+        for (int w = lane; w < P.NW; w += 64)
+            e += __popc((P.uhat[(size_t)f * P.NW + w] ^ P.u[(size_t)f * P.NW + w]) & P.info[w]);
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
+        if (lane == 0) {
+            if (P.frame_err) P.frame_err[f] = (uint32_t)e;
+            bits += (unsigned long long)e;
+            blk += (e != 0);
+        }
+    }
+    if (lane == 0 && (blk | bits)) {
+        atomicAdd(&P.counters[0], blk);
+        atomicAdd(&P.counters[1], bits);
+    }
+}
+
+}  // namespace polar

@@ -1,0 +1,502 @@
+// polar_hip.hip -- C ABI (include/polar_hip.h) over the hand-written gfx950 kernels.
+// Host side: code construction (frozen set, CRC table), kernel dispatch, buffers, stream.
+#include "../../include/polar_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bp_kernel.h"
+#include "scl_generic.h"
+
+namespace {
+
+const int kQ5G[1024] = {
+#include "q5g_table.inc"
+};
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct polar_ctx {
+    polar_cfg cfg{};
+    int n = 0, A = 0, NW = 0, logL = 0;
+    std::vector<int> info_order;          // I[]
+    std::vector<unsigned char> frozen;    // [N]
+    std::vector<int> taps;
+    std::vector<uint32_t> h_crc_tab;      // [N]
+    uint32_t *d_frozen = nullptr;         // [NW] bit = frozen
+    uint32_t *d_info = nullptr;           // [NW] bit = unfrozen
+    uint32_t *d_crc_tab = nullptr;        // [N] or null
+    uint32_t *d_frozen_override = nullptr;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 0;
+    Buf in, bits, pm, flags;              // staging for the host-pointer entry points
+    std::string last_error;
+    std::string kernel_name;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int fail(polar_ctx *c, hipError_t e, const char *what)
+{
+    if (c) c->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return POLAR_EDEVICE;
+}
+
+#define HIP_TRY(c, expr)                                   \
+    do {                                                   \
+        hipError_t e_ = (expr);                            \
+        if (e_ != hipSuccess) return fail(c, e_, #expr);   \
+    } while (0)
+
+int ensure(polar_ctx *c, Buf &b, size_t bytes)
+{
+    if (b.cap >= bytes) return POLAR_OK;
+    if (b.p) HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    HIP_TRY(c, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return POLAR_OK;
+}
+
+// Reliability order when the caller gives none: the 5G sequence restricted to < N for N <= 1024
+// (what every reference program hard-codes, SC_1024.c:42-91 / SC_128.c:41-51); for N > 1024 the
+// reference has no table and this build uses the polarization-weight (beta-expansion)
+// order, beta = 2^(1/4) -- "parity unpinned" for those sizes.
+std::vector<int> default_order(int N)
+{
+    std::vector<int> q;
+    if (N <= 1024) {
+        for (int i = 0; i < 1024; ++i)
+            if (kQ5G[i] < N) q.push_back(kQ5G[i]);
+    } else {
+        int n = 0;
+        while ((1 << n) < N) ++n;
+        std::vector<std::pair<double, int>> w(N);
+        const double beta = std::pow(2.0, 0.25);
+        for (int i = 0; i < N; ++i) {
+            double s = 0;
+            for (int b = 0; b < n; ++b)
+                if ((i >> b) & 1) s += std::pow(beta, b);
+            w[i] = {s, i};
+        }
+        std::stable_sort(w.begin(), w.end());
+        for (auto &x : w) q.push_back(x.second);
+    }
+    return q;
+}
+
+// D^i mod g(D) for i = position of leaf j in the reliability-ordered CRC codeword
+// (CRcheck, CASCL_1024_L8.c:569-598: C[i] = u_hat[I[i]], long division by g, pass iff remainder 0;
+// the remainder is linear in the bits, so it can be accumulated as bits are decided).
+std::vector<uint32_t> make_crc_table(int N, int r, const std::vector<int> &taps, const std::vector<int> &I)
+{
+    std::vector<uint32_t> tab(N, 0u);
+    uint64_t glow = 0;
+    for (int t : taps)
+        if (t < r) glow |= 1ull << t;
+    const uint64_t top = 1ull << r;
+    uint64_t rem = 1;  // D^0
+    if (r == 0) return tab;
+    for (size_t i = 0; i < I.size(); ++i) {
+        tab[I[i]] = (uint32_t)rem;
+        rem <<= 1;
+        if (rem & top) rem = (rem ^ top) ^ glow;
+    }
+    return tab;
+}
+
+template <typename R, typename IN, int LOGL>
+int launch_scl(polar_ctx *c, const polar::SclParams &P)
+{
+    auto kern = polar::k_scl_generic<R, IN, LOGL>;
+    const size_t lds = polar::scl_generic_lds_bytes<R, LOGL>(P.N);
+    if (lds > 160 * 1024) return POLAR_ENOKERNEL;
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, lds));
+    if (occ < 1) occ = 1;
+    int grid = std::min<long long>((long long)P.B, (long long)occ * c->num_cu);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, c->stream, P);
+    HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
+template <typename R, typename IN>
+int launch_scl_l(polar_ctx *c, const polar::SclParams &P)
+{
+    switch (c->logL) {
+    case 0: return launch_scl<R, IN, 0>(c, P);
+    case 1: return launch_scl<R, IN, 1>(c, P);
+    case 2: return launch_scl<R, IN, 2>(c, P);
+    case 3: return launch_scl<R, IN, 3>(c, P);
+    case 4: return launch_scl<R, IN, 4>(c, P);
+    case 5: return launch_scl<R, IN, 5>(c, P);
+    }
+    return POLAR_ENOKERNEL;
+}
+
+template <typename R, typename IN>
+int launch_bp(polar_ctx *c, const polar::BpParams &P)
+{
+    auto kern = polar::k_bp<R, IN>;
+    const size_t lds = polar::bp_lds_bytes<R>(P.N, P.n);
+    if (lds > 160 * 1024) return POLAR_ENOKERNEL;
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    const int threads = std::max(64, std::min(512, P.N / 2));
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds));
+    if (occ < 1) occ = 1;
+    int grid = std::min<long long>((long long)P.B, (long long)occ * c->num_cu);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, P);
+    HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
+int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sigma, size_t B, uint32_t *d_bits,
+                       double *d_pm, uint32_t *d_flags, const uint32_t *d_frozen)
+{
+    if (!c || !d_in || !d_bits) return POLAR_EINVAL;
+    if (B == 0) return POLAR_OK;
+    if (B > 0x7fffffffull) return POLAR_EINVAL;
+    const polar_cfg &g = c->cfg;
+    const bool f32 = g.dtype == POLAR_F32;
+    if (g.algo == POLAR_ALGO_BP) {
+        polar::BpParams P{};
+        P.in = d_in; P.sigma = sigma; P.out_bits = d_bits; P.frozen = d_frozen;
+        P.N = g.N; P.n = c->n; P.B = (int)B; P.iters = g.bp_iters;
+        if (d_pm) HIP_TRY(c, hipMemsetAsync(d_pm, 0, B * sizeof(double), c->stream));
+        if (d_flags) HIP_TRY(c, hipMemsetAsync(d_flags, 0, B * sizeof(uint32_t), c->stream));
+        if (f32) return in_is_f32 ? launch_bp<float, float>(c, P) : launch_bp<float, double>(c, P);
+        return in_is_f32 ? launch_bp<double, float>(c, P) : launch_bp<double, double>(c, P);
+    }
+    polar::SclParams P{};
+    P.in = d_in; P.sigma = sigma; P.out_bits = d_bits; P.pm = d_pm; P.flags = d_flags;
+    P.frozen = d_frozen;
+    P.crc_tab = (g.algo == POLAR_ALGO_CASCL) ? c->d_crc_tab : nullptr;
+    P.N = g.N; P.n = c->n; P.B = (int)B;
+    P.sc_mode = (g.algo == POLAR_ALGO_SC) ? 1 : 0;
+    if (f32) return in_is_f32 ? launch_scl_l<float, float>(c, P) : launch_scl_l<float, double>(c, P);
+    return in_is_f32 ? launch_scl_l<double, float>(c, P) : launch_scl_l<double, double>(c, P);
+}
+
+std::vector<uint32_t> pack_mask(const unsigned char *m, int N, bool invert)
+{
+    std::vector<uint32_t> w(N / 32, 0u);
+    for (int j = 0; j < N; ++j)
+        if ((m[j] != 0) != invert) w[j >> 5] |= 1u << (j & 31);
+    return w;
+}
+
+int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char *frozen_mask, size_t B,
+               int *u_hat, double *pm_out, unsigned *flags)
+{
+    if (!c || !in || !u_hat) return POLAR_EINVAL;
+    if (B == 0) return POLAR_OK;
+    const int N = c->cfg.N, NW = c->NW;
+    const uint32_t *d_frozen = c->d_frozen;
+    if (frozen_mask) {
+        if (c->cfg.algo == POLAR_ALGO_CASCL) return POLAR_EINVAL;
+        std::vector<uint32_t> w = pack_mask(frozen_mask, N, false);
+        if (!c->d_frozen_override) HIP_TRY(c, hipMalloc(&c->d_frozen_override, NW * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemcpyAsync(c->d_frozen_override, w.data(), NW * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                  c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // w goes out of scope
+        d_frozen = c->d_frozen_override;
+    }
+    int rc;
+    if ((rc = ensure(c, c->in, B * N * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->bits, B * NW * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->pm, B * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->flags, B * sizeof(uint32_t)))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->in.p, in, B * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    rc = decode_device_impl(c, c->in.p, 0, sigma, B, (uint32_t *)c->bits.p, (double *)c->pm.p,
+                            (uint32_t *)c->flags.p, d_frozen);
+    if (rc) return rc;
+    std::vector<uint32_t> hb(B * NW);
+    HIP_TRY(c, hipMemcpyAsync(hb.data(), c->bits.p, B * NW * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (pm_out) HIP_TRY(c, hipMemcpyAsync(pm_out, c->pm.p, B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (flags) HIP_TRY(c, hipMemcpyAsync(flags, c->flags.p, B * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t b = 0; b < B; ++b)
+        for (int j = 0; j < N; ++j) u_hat[b * N + j] = (int)((hb[b * NW + (j >> 5)] >> (j & 31)) & 1u);
+    return POLAR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *polar_version(void) { return "polar_hip 0.1 (gfx950)"; }
+
+const char *polar_strerror(int code)
+{
+    switch (code) {
+    case POLAR_OK: return "ok";
+    case POLAR_EINVAL: return "invalid argument or unsupported configuration";
+    case POLAR_ENOMEM: return "out of memory";
+    case POLAR_EDEVICE: return "HIP runtime error";
+    case POLAR_ENOKERNEL: return "no kernel instantiation for this shape";
+    }
+    return "unknown error";
+}
+
+const char *polar_last_error(const polar_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int polar_create(const polar_cfg *cfg, polar_ctx **out)
+{
+    if (!cfg || !out) return POLAR_EINVAL;
+    *out = nullptr;
+    const int N = cfg->N;
+    if (N < 32 || N > 4096 || (N & (N - 1))) return POLAR_EINVAL;
+    if (cfg->K < 1 || cfg->crc_r < 0 || cfg->crc_r > 32 || cfg->K + cfg->crc_r > N) return POLAR_EINVAL;
+    if (cfg->algo < POLAR_ALGO_SC || cfg->algo > POLAR_ALGO_CASCL) return POLAR_EINVAL;
+    if (cfg->dtype != POLAR_F64 && cfg->dtype != POLAR_F32) return POLAR_EINVAL;
+    int L = cfg->L;
+    if (cfg->algo == POLAR_ALGO_SC || cfg->algo == POLAR_ALGO_BP) L = 1;
+    if (L < 1 || L > 32 || (L & (L - 1))) return POLAR_EINVAL;
+    if (cfg->algo == POLAR_ALGO_CASCL && (cfg->crc_r < 1 || !cfg->crc_taps || cfg->n_taps < 2)) return POLAR_EINVAL;
+    if (cfg->algo == POLAR_ALGO_BP && cfg->bp_iters < 1) return POLAR_EINVAL;
+
+    polar_ctx *c = new (std::nothrow) polar_ctx();
+    if (!c) return POLAR_ENOMEM;
+    c->cfg = *cfg;
+    c->cfg.L = L;
+    c->n = 0;
+    while ((1 << c->n) < N) ++c->n;
+    c->logL = 0;
+    while ((1 << c->logL) < L) ++c->logL;
+    c->NW = N / 32;
+    const int r = (cfg->algo == POLAR_ALGO_CASCL) ? cfg->crc_r : 0;
+    c->cfg.crc_r = r;
+    c->A = cfg->K + r;
+    if (r > 0) {
+        c->taps.assign(cfg->crc_taps, cfg->crc_taps + cfg->n_taps);
+        bool has0 = false, hasr = false;
+        for (int t : c->taps) {
+            if (t < 0 || t > r) { delete c; return POLAR_EINVAL; }
+            has0 |= (t == 0);
+            hasr |= (t == r);
+        }
+        if (!has0 || !hasr) { delete c; return POLAR_EINVAL; }
+    }
+    c->cfg.crc_taps = c->taps.empty() ? nullptr : c->taps.data();
+    if (cfg->info_order) {
+        c->info_order.assign(cfg->info_order, cfg->info_order + c->A);
+    } else {
+        std::vector<int> q = default_order(N);
+        c->info_order.assign(q.end() - c->A, q.end());  // I[i] = Q[N-(K+r)+i], CASCL_1024_L8.c:214-217
+    }
+    c->cfg.info_order = c->info_order.data();
+    c->frozen.assign(N, 1);
+    for (int i = 0; i < c->A; ++i) {
+        const int j = c->info_order[i];
+        if (j < 0 || j >= N || c->frozen[j] == 0) { delete c; return POLAR_EINVAL; }
+        c->frozen[j] = 0;
+    }
+    c->h_crc_tab = make_crc_table(N, r, c->taps, c->info_order);
+
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) {
+        delete c;
+        return POLAR_EDEVICE;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, cfg->device);
+    if (e != hipSuccess) {
+        delete c;
+        return POLAR_EDEVICE;
+    }
+    c->num_cu = prop.multiProcessorCount;
+    auto cleanup = [&](int rc) {
+        polar_destroy(c);
+        return rc;
+    };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(POLAR_EDEVICE);
+    c->own_stream = true;
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return cleanup(POLAR_EDEVICE);
+    std::vector<uint32_t> fw = pack_mask(c->frozen.data(), N, false);
+    std::vector<uint32_t> iw = pack_mask(c->frozen.data(), N, true);
+    if (hipMalloc(&c->d_frozen, c->NW * 4) != hipSuccess || hipMalloc(&c->d_info, c->NW * 4) != hipSuccess)
+        return cleanup(POLAR_ENOMEM);
+    if (hipMemcpy(c->d_frozen, fw.data(), c->NW * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_info, iw.data(), c->NW * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup(POLAR_EDEVICE);
+    if (r > 0) {
+        if (hipMalloc(&c->d_crc_tab, N * 4) != hipSuccess) return cleanup(POLAR_ENOMEM);
+        if (hipMemcpy(c->d_crc_tab, c->h_crc_tab.data(), N * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup(POLAR_EDEVICE);
+    }
+    char nm[128];
+    if (cfg->algo == POLAR_ALGO_BP)
+        snprintf(nm, sizeof nm, "k_bp<%s>", cfg->dtype == POLAR_F32 ? "float" : "double");
+    else
+        snprintf(nm, sizeof nm, "k_scl_generic<%s,L=%d>", cfg->dtype == POLAR_F32 ? "float" : "double", L);
+    c->kernel_name = nm;
+    *out = c;
+    return POLAR_OK;
+}
+
+void polar_destroy(polar_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (Buf *b : {&c->in, &c->bits, &c->pm, &c->flags})
+        if (b->p) (void)hipFree(b->p);
+    if (c->d_frozen) (void)hipFree(c->d_frozen);
+    if (c->d_info) (void)hipFree(c->d_info);
+    if (c->d_crc_tab) (void)hipFree(c->d_crc_tab);
+    if (c->d_frozen_override) (void)hipFree(c->d_frozen_override);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int polar_set_stream(polar_ctx *c, void *s)
+{
+    if (!c) return POLAR_EINVAL;
+    if (c->own_stream && c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
+    c->stream = (hipStream_t)s;
+    c->own_stream = false;
+    return POLAR_OK;
+}
+
+void *polar_get_stream(polar_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int polar_synchronize(polar_ctx *c)
+{
+    if (!c) return POLAR_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return POLAR_OK;
+}
+
+int polar_ctx_info(const polar_ctx *c, int *N, int *K, int *A, int *L, int *algo, int *dtype)
+{
+    if (!c) return POLAR_EINVAL;
+    if (N) *N = c->cfg.N;
+    if (K) *K = c->cfg.K;
+    if (A) *A = c->A;
+    if (L) *L = c->cfg.L;
+    if (algo) *algo = c->cfg.algo;
+    if (dtype) *dtype = c->cfg.dtype;
+    return POLAR_OK;
+}
+
+const char *polar_kernel_name(const polar_ctx *c) { return c ? c->kernel_name.c_str() : ""; }
+
+int polar_decode_device(polar_ctx *c, const void *d_in, int in_is_f32, double sigma, size_t B, uint32_t *d_bits,
+                        double *d_pm, uint32_t *d_flags)
+{
+    if (!c) return POLAR_EINVAL;
+    return decode_device_impl(c, d_in, in_is_f32, sigma, B, d_bits, d_pm, d_flags, c->d_frozen);
+}
+
+int polar_decode_batch(polar_ctx *c, const double *llr_in, const unsigned char *frozen_mask, size_t B, int *u_hat,
+                       double *pm_out, unsigned *flags)
+{
+    return host_batch(c, llr_in, 0.0, frozen_mask, B, u_hat, pm_out, flags);
+}
+
+int polar_decode_batch_y(polar_ctx *c, const double *y, double sigma, size_t B, int *u_hat, double *pm_out,
+                         unsigned *flags)
+{
+    if (!(sigma > 0)) return POLAR_EINVAL;
+    return host_batch(c, y, sigma, nullptr, B, u_hat, pm_out, flags);
+}
+
+int polar_decode(polar_ctx *c, const double *y, double sigma, int *u_hat)
+{
+    if (!(sigma > 0)) return POLAR_EINVAL;
+    return host_batch(c, y, sigma, nullptr, 1, u_hat, nullptr, nullptr);
+}
+
+int polar_decode_llr(const double *llr_in, const unsigned char *frozen_mask, int N, int L, int *u_hat)
+{
+    if (!llr_in || !frozen_mask || !u_hat) return POLAR_EINVAL;
+    static std::mutex mu;
+    static std::vector<std::pair<std::vector<unsigned char>, polar_ctx *>> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    std::vector<unsigned char> key(frozen_mask, frozen_mask + N);
+    key.push_back((unsigned char)L);
+    polar_ctx *c = nullptr;
+    for (auto &kv : cache)
+        if (kv.first == key) c = kv.second;
+    if (!c) {
+        std::vector<int> info;
+        for (int j = 0; j < N; ++j)
+            if (!frozen_mask[j]) info.push_back(j);
+        if (info.empty()) return POLAR_EINVAL;
+        polar_cfg g{};
+        g.N = N; g.K = (int)info.size(); g.L = L;
+        g.algo = (L == 1) ? POLAR_ALGO_SC : POLAR_ALGO_SCL;
+        g.info_order = info.data();
+        g.dtype = POLAR_F64;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        g.device = dev;
+        int rc = polar_create(&g, &c);
+        if (rc) return rc;
+        if (cache.size() >= 8) {
+            polar_destroy(cache.front().second);
+            cache.erase(cache.begin());
+        }
+        cache.emplace_back(key, c);
+    }
+    return host_batch(c, llr_in, 0.0, nullptr, 1, u_hat, nullptr, nullptr);
+}
+
+int polar_count_errors_device(polar_ctx *c, const uint32_t *d_uhat, const uint32_t *d_u, size_t B,
+                              unsigned long long *d_counters, uint32_t *d_frame_err)
+{
+    if (!c || !d_uhat || !d_u || !d_counters) return POLAR_EINVAL;
+    if (B == 0) return POLAR_OK;
+    polar::CountParams P{d_uhat, d_u, c->d_info, d_counters, d_frame_err, c->NW, (int)B};
+    const int waves_per_block = 4;
+    int grid = (int)std::min<size_t>((B + waves_per_block - 1) / waves_per_block, (size_t)c->num_cu * 8);
+    hipLaunchKernelGGL(polar::k_count_errors, dim3(grid), dim3(64 * waves_per_block), 0, c->stream, P);
+    HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
+int polar_time_decode_device(polar_ctx *c, const void *d_in, int in_is_f32, double sigma, size_t B,
+                             uint32_t *d_bits, int reps, float *ms)
+{
+    if (!c || !ms || reps < 1) return POLAR_EINVAL;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < reps; ++i) {
+        int rc = decode_device_impl(c, d_in, in_is_f32, sigma, B, d_bits, nullptr, nullptr, c->d_frozen);
+        if (rc) return rc;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    float t = 0;
+    HIP_TRY(c, hipEventElapsedTime(&t, c->ev0, c->ev1));
+    *ms = t / (float)reps;
+    return POLAR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference decoders.
+
+Run in the build container (needs /root/reference and `make -C oracle ref`):
+
+    python tests/golden/make_golden.py
+
+For every reference simulator (SC_128 ... CASCL_1024_L8) it draws seeded frames with the
+reference's own transmit chain (restated in oracle/polar_oracle.c and pinned by the published run
+counts), calls the reference's decode function compiled from /root/reference (oracle/_ref/), and
+stores inputs + outputs:
+
+    <name>.npz : sigma[F], y[F][N] f64, u[F][N] u8 (sent), u_hat[F][N] u8 (reference decision),
+                 pm[F] f64 (metric of the chosen path; 0 for SC/BP)
+
+It also parses the reference's published fixed-seed logs (myResult_*.zip: data, not code) into
+published_runs.json: the known-answer run counts used by tests/test_oracle_kat.py.
+Only data is written here; no reference source text.
+"""
+import json
+import os
+import re
+import sys
+import zipfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from oracle import oracle_py as O  # noqa: E402
+
+REF = "/root/reference"
+SNRS = (1.0, 2.0, 3.0)
+
+
+def make_vectors():
+    for name, (N, K, taps, algo, L) in O.REF_PROGRAMS.items():
+        code = O.Code(N, K, taps)
+        ref = O.Ref(name)
+        per = 8 if N == 1024 else 32
+        if algo == "BP" and N == 1024:
+            per = 4
+        sim = O.Sim(20261004 + N + len(name))
+        sig, ys, us, uhs, pms = [], [], [], [], []
+        for db in SNRS:
+            s = O.sigma_from_db(db)
+            for _ in range(per):
+                u, y = sim.frame(code, s)
+                uh, pm = ref.decode(y, s)
+                sig.append(s); ys.append(y); us.append(u); uhs.append(uh); pms.append(pm)
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"),
+                            sigma=np.array(sig), y=np.array(ys), u=np.array(us, dtype=np.uint8),
+                            u_hat=np.array(uhs, dtype=np.uint8), pm=np.array(pms))
+        nerr = sum(int((a != b).any()) for a, b in zip(us, uhs))
+        print(f"{name}: {len(sig)} frames, {nerr} in error")
+
+
+def parse_log(text):
+    """-> list of blocks {seed, L, rows:[(snr, errblock, run)]}"""
+    blocks, cur = [], None
+    seed = None
+    for line in text.replace("\r", "").split("\n"):
+        m = re.match(r"\s*SEED = (\d+)", line)
+        if m:
+            seed = int(m.group(1))
+            cur = None
+            continue
+        m = re.search(r"bSNR = ([\d.]+)\s+error block = (\d+)\s+run = (\d+)", line)
+        if not m:
+            continue
+        lm = re.match(r"\s*L = (\d+)", line)
+        Lv = int(lm.group(1)) if lm else 1
+        if cur is None or cur["L"] != Lv or cur["seed"] != seed:
+            cur = {"seed": seed, "L": Lv, "rows": []}
+            blocks.append(cur)
+        cur["rows"].append((float(m.group(1)), int(m.group(2)), int(m.group(3))))
+    return blocks
+
+
+def make_published():
+    out = {}
+    for zn, members in (("myResult_1024", ["SC1024out.dat", "SCL1024out.dat", "CASCL_L8.dat"]),
+                        ("myResult_128", ["SC128out.txt", "SCL128out_errblock50.dat", "CASCL_128_L8.txt"])):
+        z = zipfile.ZipFile(os.path.join(REF, zn + ".zip"))
+        for mname in members:
+            text = z.read(f"{zn}/{mname}").decode("utf-8", "replace")
+            out[f"{zn}/{mname}"] = parse_log(text)
+    # seeds the logs do not print but the sources fix (SC_128.c:35, SCL_128.c:36: SEED = 1024)
+    for key in ("myResult_128/SC128out.txt", "myResult_128/SCL128out_errblock50.dat"):
+        for b in out[key]:
+            if b["seed"] is None:
+                b["seed"] = 1024
+    with open(os.path.join(HERE, "published_runs.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("published_runs.json:", {k: len(v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    make_vectors()
+    make_published()
