@@ -45,6 +45,12 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime: it must be the first one loaded in the process, or torch later
+    # finds "No HIP GPUs".  torch is only plumbing here (device buffers, streams, distributed).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise PolarError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")

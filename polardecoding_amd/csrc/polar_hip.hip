@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "bp_kernel.h"
+#include "scl_fast.h"
 #include "scl_generic.h"
 
 namespace {
@@ -46,6 +47,7 @@ struct polar_ctx {
     Buf in, bits, pm, flags;              // staging for the host-pointer entry points
     std::string last_error;
     std::string kernel_name;
+    bool force_generic = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -153,6 +155,45 @@ int launch_scl_l(polar_ctx *c, const polar::SclParams &P)
     return POLAR_ENOKERNEL;
 }
 
+
+// tuned instantiations: L = 8, N in {128, 1024}
+template <typename R, typename IN, int NLOG, bool CRC_ON>
+int launch_fast(polar_ctx *c, const polar::SclParams &P)
+{
+    auto kern = polar::k_scl_fast<R, IN, NLOG, CRC_ON>;
+    constexpr int WAVES = polar::FastCfg<R, NLOG>::WAVES;
+    const size_t lds = polar::FastCfg<R, NLOG>::total;
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WAVES, lds));
+    if (occ < 1) occ = 1;
+    long long blocks_needed = ((long long)P.B + WAVES - 1) / WAVES;
+    int grid = (int)std::min<long long>(blocks_needed, (long long)occ * c->num_cu);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, c->stream, P);
+    HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
+template <typename R, typename IN>
+int launch_fast_n(polar_ctx *c, const polar::SclParams &P, bool crc)
+{
+    if (P.N == 1024) return crc ? launch_fast<R, IN, 10, true>(c, P) : launch_fast<R, IN, 10, false>(c, P);
+    if (P.N == 128) return crc ? launch_fast<R, IN, 7, true>(c, P) : launch_fast<R, IN, 7, false>(c, P);
+    return POLAR_ENOKERNEL;
+}
+
+bool fast_ok(const polar_ctx *c, int in_is_f32)
+{
+    const polar_cfg &g = c->cfg;
+    if (c->force_generic) return false;
+    if (g.algo != POLAR_ALGO_SCL && g.algo != POLAR_ALGO_CASCL) return false;
+    if (g.L != 8 || (g.N != 1024 && g.N != 128)) return false;
+    if (g.dtype == POLAR_F64 && in_is_f32) return false;
+    return true;
+}
+
 template <typename R, typename IN>
 int launch_bp(polar_ctx *c, const polar::BpParams &P)
 {
@@ -195,6 +236,11 @@ int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sig
     P.crc_tab = (g.algo == POLAR_ALGO_CASCL) ? c->d_crc_tab : nullptr;
     P.N = g.N; P.n = c->n; P.B = (int)B;
     P.sc_mode = (g.algo == POLAR_ALGO_SC) ? 1 : 0;
+    if (fast_ok(c, in_is_f32)) {
+        const bool crc = g.algo == POLAR_ALGO_CASCL;
+        if (!f32) return launch_fast_n<double, double>(c, P, crc);
+        return in_is_f32 ? launch_fast_n<float, float>(c, P, crc) : launch_fast_n<float, double>(c, P, crc);
+    }
     if (f32) return in_is_f32 ? launch_scl_l<float, float>(c, P) : launch_scl_l<float, double>(c, P);
     return in_is_f32 ? launch_scl_l<double, float>(c, P) : launch_scl_l<double, double>(c, P);
 }
@@ -352,6 +398,11 @@ int polar_create(const polar_cfg *cfg, polar_ctx **out)
     else
         snprintf(nm, sizeof nm, "k_scl_generic<%s,L=%d>", cfg->dtype == POLAR_F32 ? "float" : "double", L);
     c->kernel_name = nm;
+    if (const char *e = getenv("POLAR_FORCE_GENERIC")) c->force_generic = (e[0] == '1');
+    if (fast_ok(c, cfg->dtype == POLAR_F32)) {
+        snprintf(nm, sizeof nm, "k_scl_fast<%s,N=%d,L=8>", cfg->dtype == POLAR_F32 ? "float" : "double", N);
+        c->kernel_name = nm;
+    }
     *out = c;
     return POLAR_OK;
 }

@@ -1,0 +1,663 @@
+// scl_fast.h -- tuned SCL / CA-SCL kernel for list size 8 (S = 8 lanes per path), N = 2^NLOG.
+//
+// One codeword per wavefront, 4 independent wavefronts per workgroup (no inter-wave barrier in
+// the decode loop).  Lane = (path p = lane/8, position pos = lane%8).  What the measurements in
+// profiles/r01_ubench_gfx950.txt dictate ("VALU budget"):
+//   * f64 VALU ops cost 2 issue slots, and 4x that when <= 8 lanes are enabled  -> nothing in the
+//     decode loop is EXEC-masked: every lane always executes, idle lanes carry don't-care data;
+//   * every v_cmp / v_cndmask / v_addc costs 2 slots, so the reference's 8-level staircase
+//     (7 compares per look-up, two look-ups per CHK) is replaced by ONE exact compare per look-up:
+//     the operand's exponent + 3 mantissa bits select a cell of a 50-entry LDS table holding the
+//     only threshold that can lie in that cell and the number of thresholds below it;
+//     T(s) - T(d) comes from an 8x8 LDS table of the IEEE differences (bit-exact by construction);
+//   * LDS capacity, not bandwidth, limits waves/CU -> all per-path LLR levels live in REGISTERS:
+//       level t >= 4 : 2^t/8 registers per lane, element e = pos + 8 r        (A[2^t/8 + r])
+//       level t <= 3 : one register per lane (a3, a2, a1), element e = pos
+//     only the channel vector, the single-path left child of the root (computed before the first
+//     fork) and the bit-packed partial sums of levels >= 5 are in LDS (~14 KB per codeword);
+//   * the reference's copyPath/simpleCopy (SCL_1024.c:451-478) is replaced by lazy pointers for
+//     levels >= 4 (a g-step reads its source level from the owning path's lanes with
+//     ds_bpermute; f-steps always read the lane's own registers) and by an eager 3-register
+//     shuffle for levels <= 3;
+//   * while fewer than L paths exist (phase 1, SCL_1024.c:581-605) the idle lane groups run as
+//     replicas (group q mirrors slot q mod act), so a fork needs no copy at all;
+//   * u_hat is not stored per path: x_hat = root partial sums of the winner, u_hat = x_hat F^{(x)n};
+//   * every step body exists once in the code (uniform branches on the leaf index), so the kernel
+//     stays inside the instruction cache.
+// Arithmetic order is the reference's (polar_math.h); results are bit-identical to k_scl_generic.
+#pragma once
+#include "polar_math.h"
+#include "scl_generic.h"
+
+namespace polar {
+
+// ---- cross-lane helpers -----------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int K>  // lane i <- lane i+K within its row of 16 (row_shl)
+__device__ __forceinline__ double shl_lanes(double x)
+{
+    long long b = __double_as_longlong(x);
+    int lo = dpp_i<0x100 + K>((int)b), hi = dpp_i<0x100 + K>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int K>
+__device__ __forceinline__ float shl_lanes(float x)
+{
+    return __int_as_float(dpp_i<0x100 + K>(__float_as_int(x)));
+}
+template <int K>  // lane i <- lane i-K within its row (row_shr)
+__device__ __forceinline__ double shr_lanes(double x)
+{
+    long long b = __double_as_longlong(x);
+    int lo = dpp_i<0x110 + K>((int)b), hi = dpp_i<0x110 + K>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int K>
+__device__ __forceinline__ float shr_lanes(float x)
+{
+    return __int_as_float(dpp_i<0x110 + K>(__float_as_int(x)));
+}
+
+__device__ __forceinline__ void lds_fence() { __asm__ volatile("" ::: "memory"); }
+
+// ---- table-driven staircase -----------------------------------------------------------------------
+// cell(x) for x >= 0: 0 for x < 0.125, 1..48 = 8 cells per binade over [0.125, 8), 49 for x >= 8.
+// The seven thresholds 0.196 .. 4.5 (SCL_1024.c:352-358) fall into seven different cells.
+template <typename R>
+struct Cell;
+template <>
+struct Cell<double> {
+    struct __attribute__((aligned(16))) Entry { double thr; int base; int pad; double tlo, thi; };
+    static __device__ __forceinline__ int of(double x)
+    {
+        const int t = ((__double2hiint(x) & 0x7fffffff) - 0x3FC00000) >> 17;
+        return min(max(t, -1), 48) + 1;
+    }
+};
+template <>
+struct Cell<float> {
+    struct __attribute__((aligned(16))) Entry { float thr; int base; float tlo, thi; };
+    static __device__ __forceinline__ int of(float x)
+    {
+        const int t = ((__float_as_int(x) & 0x7fffffff) - 0x3E000000) >> 20;
+        return min(max(t, -1), 48) + 1;
+    }
+};
+
+template <typename R>
+struct Lut {
+    using Entry = typename Cell<R>::Entry;
+    static constexpr int NCELL = 50;
+    static constexpr size_t bytes = ((sizeof(Entry) * NCELL + 15) / 16) * 16 + sizeof(R) * 64;
+    const Entry *cells;
+    const R *dlt;  // dlt[i*8+j] = T_i - T_j (one IEEE subtraction, like `delta = T(s); delta -= T(d)`)
+
+    __device__ __forceinline__ void bind(unsigned char *base)
+    {
+        cells = reinterpret_cast<const Entry *>(base);
+        dlt = reinterpret_cast<const R *>(base + ((sizeof(Entry) * NCELL + 15) / 16) * 16);
+    }
+    // executed by a whole workgroup before its first barrier
+    static __device__ void build(unsigned char *base, int tid, int nthreads)
+    {
+        Entry *c = reinterpret_cast<Entry *>(base);
+        R *d = reinterpret_cast<R *>(base + ((sizeof(Entry) * NCELL + 15) / 16) * 16);
+        const R thr[7] = {R(0.196), R(0.433), R(0.71), R(1.05), R(1.508), R(2.252), R(4.5)};
+        const R tv[8] = {R(0.65), R(0.55), R(0.45), R(0.35), R(0.25), R(0.15), R(0.05), R(0)};
+        for (int i = tid; i < NCELL; i += nthreads) {
+            int base_cnt = 0;
+            R t = R(__builtin_huge_val());
+            for (int k = 0; k < 7; ++k) {
+                const int ck = Cell<R>::of(thr[k]);
+                if (ck < i) ++base_cnt;
+                if (ck == i) t = thr[k];
+            }
+            c[i].thr = t;
+            c[i].base = base_cnt;
+            c[i].tlo = tv[base_cnt];
+            c[i].thi = tv[base_cnt < 7 ? base_cnt + 1 : 7];
+        }
+        for (int i = tid; i < 64; i += nthreads) d[i] = tv[i >> 3] - tv[i & 7];
+    }
+    // number of thresholds <= |x|
+    __device__ __forceinline__ int idx(R x) const
+    {
+        const Entry *e = cells + Cell<R>::of(x);
+        const R thr = e->thr;
+        const int base = e->base;
+        return base + ((absr(x) >= thr) ? 1 : 0);
+    }
+    // T(|x|) in one LDS round trip
+    __device__ __forceinline__ R tabv(R x) const
+    {
+        const Entry *e = cells + Cell<R>::of(x);
+        const R thr = e->thr, lo = e->tlo, hi = e->thi;
+        return (absr(x) >= thr) ? hi : lo;
+    }
+};
+
+__device__ __forceinline__ double xor_sign(double m, double a, double b)
+{
+    const int s = (__double2hiint(a) ^ __double2hiint(b)) & 0x80000000;
+    return __hiloint2double(__double2hiint(m) ^ s, __double2loint(m));
+}
+__device__ __forceinline__ float xor_sign(float m, float a, float b)
+{
+    const int s = (__float_as_int(a) ^ __float_as_int(b)) & 0x80000000;
+    return __int_as_float(__float_as_int(m) ^ s);
+}
+__device__ __forceinline__ double minabs(double a, double b) { return __builtin_fmin(__builtin_fabs(a), __builtin_fabs(b)); }
+__device__ __forceinline__ float minabs(float a, float b) { return __builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b)); }
+
+// CHK (SCL_1024.c:343-374) with the staircase taken from the tables.  sign(a)sign(b) is applied by
+// xor of the sign bits: for a = -0.0 the reference uses +1, but then min = 0 and delta = +0, and
+// (+-0) + (+0) = +0 either way, so the result is identical.
+template <typename R>
+__device__ __forceinline__ R chk_lut(R a, R b, const Lut<R> &L)
+{
+    const R s = a + b, d = a - b;
+    const int is = L.idx(s), id = L.idx(d);
+    const R delta = L.dlt[is * 8 + id];
+    return xor_sign(minabs(a, b), a, b) + delta;
+}
+
+// negate x when bit 31 of `m` is set (m & 0x80000000 pre-masked): g = cL + (bit ? -cU : cU)
+__device__ __forceinline__ double flip(double x, uint32_t m) { return __hiloint2double(__double2hiint(x) ^ (int)m, __double2loint(x)); }
+__device__ __forceinline__ float flip(float x, uint32_t m) { return __int_as_float(__float_as_int(x) ^ (int)m); }
+// lower-node update with the partner bit at bit position `sh` of w (SCL_1024.c:412-416): cL +- cU
+template <typename R>
+__device__ __forceinline__ R g_bit(R cU, R cL, uint32_t w, int sh)
+{
+    return cL + flip(cU, (w << (31 - sh)) & 0x80000000u);
+}
+
+template <typename R, int NLOG>
+struct FastCfg {
+    static constexpr int N = 1 << NLOG;
+    static constexpr int NW = N / 32;
+    static constexpr int TOP = NLOG - 1;      // virtual level (never stored per path)
+    static constexpr int HI = NLOG - 2;       // highest register level
+    static constexpr int NA = (1 << HI) / 4;  // registers for levels 4..HI (level t at offset 2^t/8)
+    static constexpr int WAVES = 4;
+    // block-shared LDS
+    static constexpr size_t off_lut = 0;
+    static constexpr size_t off_frz = off_lut + ((Lut<R>::bytes + 15) / 16) * 16;   // frozen words [NW]
+    static constexpr size_t off_crc = off_frz + 4 * NW;                             // crc table [N]
+    static constexpr size_t shared_bytes = off_crc + 4 * N;
+    // per-wave LDS
+    static constexpr size_t off_ch = 0;
+    static constexpr size_t off_tl = off_ch + sizeof(R) * N;        // top-left level (N/2)
+    static constexpr size_t off_bl = off_tl + sizeof(R) * (N / 2);  // saved partial sums [8][NW]
+    static constexpr size_t off_cw = off_bl + 4 * 8 * NW;           // working partial sums [8][NW]
+    static constexpr size_t off_cd = off_cw + 4 * 8 * NW;           // candidates [16] (exact fall-back)
+    static constexpr size_t off_ky = off_cd + sizeof(R) * 16;       // candidate keys [16] u32
+    static constexpr size_t per_wave = off_ky + 64;
+    static constexpr size_t total = shared_bytes + WAVES * per_wave;
+};
+
+// 32-bit ordering key of a non-negative metric: f32 bits are exact, the high word of an f64 is exact
+// unless two candidates share it across the survivor boundary (then the exact fall-back runs)
+__device__ __forceinline__ uint32_t metric_key(double x) { return (uint32_t)__double2hiint(x); }
+__device__ __forceinline__ uint32_t metric_key(float x) { return (uint32_t)__float_as_int(x); }
+
+template <typename R, int NLOG, bool CRC_ON>
+struct FastDec {
+    using C = FastCfg<R, NLOG>;
+    static constexpr int N = C::N, NW = C::NW, TOP = C::TOP, HI = C::HI, L = 8;
+    static constexpr int NFA = HI - 3;  // pointer fields for LLR levels 4..HI; partial-sum levels 5..TOP follow
+
+    // ---- per-lane state ----
+    R A[C::NA];      // levels 4..HI
+    R a3, a2, a1;    // levels 3..1 (element pos)
+    R PM;            // valid at pos 0
+    uint32_t ptr;    // 3 bits per field: LLR level t -> field t-4; partial sums of level t -> field NFA + t-5
+    uint32_t crc, bl0;
+    uint32_t fl;
+    int logact;      // log2(number of distinct paths); groups are replicas while < 3
+    int p, pos, lane;
+    int own_addr, oth_addr;  // byte addresses into keys[] for the rank network
+    Lut<R> lut;
+    // LDS
+    R *ch, *tl, *cand;
+    uint32_t *blw, *curw, *keys;
+    const uint32_t *crct;
+
+    __device__ __forceinline__ int pa(int t) const { return (ptr >> (3 * (t - 4))) & 7; }
+    __device__ __forceinline__ void set_pa(int t, int v) { ptr = (ptr & ~(7u << (3 * (t - 4)))) | ((uint32_t)v << (3 * (t - 4))); }
+    __device__ __forceinline__ int pb(int t) const { return (ptr >> (3 * (NFA + t - 5))) & 7; }
+    __device__ __forceinline__ void set_pb(int t, int v) { ptr = (ptr & ~(7u << (3 * (NFA + t - 5)))) | ((uint32_t)v << (3 * (NFA + t - 5))); }
+
+    __device__ __forceinline__ R chk(R a, R b) const { return chk_lut<R>(a, b, lut); }
+
+    // ---- f steps on own registers ----
+    template <int T>  // T in [4, HI-1]: level T from level T+1
+    __device__ __forceinline__ void f_up()
+    {
+        constexpr int RO = (1 << T) / 8;
+#pragma unroll
+        for (int r = 0; r < RO; ++r) A[RO + r] = chk(A[2 * RO + r], A[3 * RO + r]);
+        set_pa(T, p);
+    }
+
+    // ---- g steps: level T from level T+1 of the owning path (bpermute), partial sums beta_T ----
+    template <int T>  // T in [4, HI-1]
+    __device__ __forceinline__ void g_up()
+    {
+        constexpr int RO = (1 << T) / 8;
+        const int sl = pa(T + 1) * 8 + pos;
+        if constexpr (T >= 5) {
+            const uint32_t *bw = blw + pb(T) * NW + (1 << (T - 5));
+#pragma unroll
+            for (int r4 = 0; r4 < RO / 4; ++r4) {
+                const uint32_t w = bw[r4] >> pos;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = r4 * 4 + k;
+                    const R x = __shfl(A[2 * RO + r], sl), y = __shfl(A[3 * RO + r], sl);
+                    A[RO + r] = g_bit<R>(x, y, w, 8 * k);
+                }
+            }
+        } else {  // T == 4: bits 16 + e in bl0
+            const uint32_t w = bl0 >> (16 + pos);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const R x = __shfl(A[4 + r], sl), y = __shfl(A[6 + r], sl);
+                A[2 + r] = g_bit<R>(x, y, w, 8 * r);
+            }
+        }
+        set_pa(T, p);
+    }
+
+    // Level HI from the top level.  right: j >= N/2 (virtual top level from ch and beta_TOP), else the stored
+    // top-left array.  gstep: g (with beta_HI) instead of f.  The level-HI registers are rotated so that the
+    // body exists once in the code.
+    __device__ __forceinline__ void top_to_hi(bool right, bool gstep)
+    {
+        constexpr int RO = (1 << HI) / 8;  // registers of level HI
+        constexpr int H = 1 << HI;         // pair distance in elements
+        const uint32_t *bt = blw + pb(TOP) * NW + (1 << (TOP - 5));
+        const uint32_t *bh = blw + pb(HI) * NW + (1 << (HI - 5));
+        constexpr int CH = RO < 8 ? RO : 8;  // registers produced per pass
+        for (int q = 0; q < RO / CH; ++q) {
+            R out[CH];
+#pragma unroll
+            for (int h4 = 0; h4 < CH / 4; ++h4) {
+                const int r4 = q * (CH / 4) + h4;
+                const uint32_t wt0 = bt[r4] >> pos, wt1 = bt[H / 32 + r4] >> pos, wh = bh[r4] >> pos;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = pos + 8 * (r4 * 4 + k);
+                    R x, y;
+                    if (right) {
+                        x = g_bit<R>(ch[e], ch[e + N / 2], wt0, 8 * k);
+                        y = g_bit<R>(ch[e + H], ch[e + H + N / 2], wt1, 8 * k);
+                    } else {
+                        x = tl[e];
+                        y = tl[e + H];
+                    }
+                    out[h4 * 4 + k] = gstep ? g_bit<R>(x, y, wh, 8 * k) : chk(x, y);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RO - CH; ++r) A[RO + r] = A[RO + r + CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) A[2 * RO - CH + k] = out[k];
+        }
+        set_pa(HI, p);
+    }
+
+    template <int T>
+    __device__ __forceinline__ void f_chain_up(int d)
+    {
+        if constexpr (T >= 4) {
+            if (d > T) f_up<T>();
+            f_chain_up<T - 1>(d);
+        }
+    }
+    template <int T>
+    __device__ __forceinline__ void g_select(int d)
+    {
+        if constexpr (T >= 4) {
+            if (d == T) g_up<T>();
+            else g_select<T - 1>(d);
+        }
+    }
+    // Head of octet o (leaves 8o .. 8o+7): g at level d = ctz(8o) (root f for o = 0), f chain down to level 3.
+    // Each step body appears once; the branches are uniform.
+    __device__ __forceinline__ void octet_head(int o)
+    {
+        const int d = (o == 0) ? NLOG : 3 + __builtin_ctz((unsigned)o);
+        if (d >= HI) {
+            top_to_hi(/*right=*/o >= N / 16, /*gstep=*/d == HI);
+        } else if (d >= 4) {
+            g_select<HI - 1>(d);
+        } else {
+            const int sl = pa(4) * 8 + pos;
+            a3 = g_bit<R>(__shfl(A[2], sl), __shfl(A[3], sl), bl0, 8 + pos);
+        }
+        f_chain_up<HI - 1>(d);
+        if (d > 3) a3 = chk(A[2], A[3]);
+    }
+
+    // ---- partial sums (updateBit, SCL_1024.c:424-448), bit positions static inside an octet ----
+    template <int K>
+    __device__ __forceinline__ void set_bit_k(int o, uint32_t bit)
+    {
+        if constexpr ((K & 1) == 0) {
+            bl0 = (bl0 & ~2u) | (bit << 1);  // left child at level 0
+        } else if constexpr ((K & 3) == 1) {
+            const uint32_t c1 = (((bl0 >> 1) & 1u) ^ bit) | (bit << 1);
+            bl0 = (bl0 & ~0xCu) | (c1 << 2);
+        } else if constexpr (K == 3) {
+            const uint32_t c1 = (((bl0 >> 1) & 1u) ^ bit) | (bit << 1);
+            const uint32_t c2 = (((bl0 >> 2) & 3u) ^ c1) | (c1 << 2);
+            bl0 = (bl0 & ~0xF0u) | (c2 << 4);
+        } else {
+            set_bit_tail(8 * o + 7, bit);
+        }
+    }
+    __device__ __forceinline__ void set_bit_tail(int j, uint32_t bit)
+    {
+        uint32_t cur = bit;
+        const int z = __builtin_ctz(~(unsigned)j);  // trailing ones of j (uniform), >= 3 here
+        const int zl = z < 5 ? z : 5;
+        for (int t = 0; t < zl; ++t) {
+            const int h = 1 << t;
+            const uint32_t mask = (1u << h) - 1u;
+            const uint32_t l = (bl0 >> h) & mask;
+            cur = (l ^ (cur & mask)) | ((cur & mask) << h);
+        }
+        if (z < 5) {
+            const int h = 1 << z;
+            const uint32_t mask = (1u << h) - 1u;
+            bl0 = (bl0 & ~(mask << h)) | ((cur & mask) << h);
+            return;
+        }
+        // rare path (every 32 leaves): levels >= 5 are words in LDS
+        lds_fence();
+        if (pos == 0) curw[p * NW] = cur;
+        lds_fence();
+        int t = 5;
+        while (t < NLOG && ((j >> t) & 1)) {
+            const int nw = 1 << (t - 5);
+            const int sb = pb(t);
+            for (int w = pos; w < nw; w += 8) {
+                const uint32_t c = curw[p * NW + w];
+                const uint32_t l = blw[sb * NW + nw + w];
+                curw[p * NW + w] = l ^ c;
+                curw[p * NW + w + nw] = c;
+            }
+            lds_fence();
+            ++t;
+        }
+        if (t < NLOG) {
+            const int nw = 1 << (t - 5);
+            for (int w = pos; w < nw; w += 8) blw[p * NW + nw + w] = curw[p * NW + w];
+            set_pb(t, p);
+            lds_fence();
+        }
+    }
+
+    // ---- survivors of the 2L candidates (SCL_1024.c:612-633) ----
+    // Returns the 16-bit mask (bit p: 0-branch of slot p survives, bit 8+p: 1-branch).  Strict "< med" with
+    // med the (L+1)-th smallest  <=>  #{m : c_m <= c} <= L.  Rank network: the 16 keys sit in every row of 16
+    // lanes; row r compares its keys with the row rotated by 4r .. 4r+3, the four rows add up.
+    __device__ __forceinline__ uint32_t survivors(R c0, R c1)
+    {
+        lds_fence();
+        if (pos == 0) {
+            keys[2 * p] = metric_key(c0);
+            keys[2 * p + 1] = metric_key(c1);
+        }
+        lds_fence();
+        const uint32_t own = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(keys) + own_addr);
+        const uint32_t oth = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(keys) + oth_addr);
+        uint32_t cnt = (oth <= own) ? 1u : 0u;
+        cnt += ((uint32_t)dpp_i<0x121>((int)oth) <= own) ? 1u : 0u;  // row_ror:1
+        cnt += ((uint32_t)dpp_i<0x122>((int)oth) <= own) ? 1u : 0u;
+        cnt += ((uint32_t)dpp_i<0x123>((int)oth) <= own) ? 1u : 0u;
+        {
+            auto r = __builtin_amdgcn_permlane16_swap(cnt, cnt, false, false);
+            cnt = r[0] + r[1];
+            auto q = __builtin_amdgcn_permlane32_swap(cnt, cnt, false, false);
+            cnt = q[0] + q[1];
+        }
+        uint32_t mask = (uint32_t)__ballot(cnt <= (uint32_t)L) & 0xFFFFu;
+        if (sizeof(R) == 8 && __popc(mask) != L) {
+            // keys tie across the boundary (or a true median tie): decide on the full metrics
+            lds_fence();
+            if (pos == 0) {
+                cand[p] = c0;
+                cand[8 + p] = c1;
+            }
+            lds_fence();
+            const R mine = cand[lane & 15];
+            int n = 0;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) n += (cand[m] <= mine) ? 1 : 0;
+            mask = (uint32_t)__ballot(n <= L) & 0xFFFFu;
+        }
+        return mask;
+    }
+
+    // ---- decision at leaf j = 8o + K given lambda (valid at pos 0) ----
+    template <int K>
+    __device__ __forceinline__ void decide(int o, bool frozen, R lam)
+    {
+        const int j = 8 * o + K;
+        uint32_t crcw = 0;
+        if (CRC_ON && !frozen) crcw = crct[j];
+        uint32_t bit = 0;
+        const R absl = absr(lam);
+        const R tt = lut.tabv(lam);
+        const R pen = tt + absl;
+        const R ph0 = (lam < R(0)) ? pen : tt;  // PHI(.,0)  (SCL_1024.c:481-502)
+        if (frozen) {
+            PM += ph0;  // SCL_1024.c:601-604, :662-665
+        } else {
+            const R ph1 = (lam > R(0)) ? pen : tt;  // PHI(.,1)
+            if (logact < 3) {
+                // phase 1 (SCL_1024.c:586-600): group q is slot q mod 2^logact; the fork sends the replicas
+                // with bit `logact` of q set down the 1-branch
+                bit = (p >> logact) & 1;
+                PM += bit ? ph1 : ph0;
+                ++logact;
+            } else {
+                // phase 2 (SCL_1024.c:610-661)
+                const R c0 = PM + ph0, c1 = PM + ph1;
+                const uint32_t mask = survivors(c0, c1);
+                const uint32_t m0 = mask & 0xFFu, m1 = mask >> 8;
+                const uint32_t m_both = m0 & m1, m_dead = ~(m0 | m1) & 0xFFu;
+                if (__popc(mask) < L) fl |= 0x1u;  // median tie ("Oops!", :621-622)
+                const bool s0 = (m0 >> p) & 1, s1 = (m1 >> p) & 1;
+                if (m_dead == 0u) {
+                    bit = (!s0 && s1) ? 1u : 0u;  // every slot keeps exactly one branch: no copy
+                    PM = bit ? c1 : c0;
+                } else {
+                    // m-th both-survivor (ascending slot) forks into the m-th dead slot (:636-661)
+                    const bool dead = !s0 && !s1;
+                    const int myrank = __popc(m_dead & ((1u << p) - 1u));
+                    int sg = p;
+                    bool refilled = false;
+                    {
+                        uint32_t bm = m_both;
+                        int k = 0;
+                        while (bm) {
+                            const int b = __builtin_ctz(bm);
+                            if (dead && k == myrank) {
+                                sg = b;
+                                refilled = true;
+                            }
+                            bm &= bm - 1;
+                            ++k;
+                        }
+                    }
+                    const int sl = sg * 8 + pos;
+                    const R c1s = __shfl(c1, sl);
+                    ptr = __shfl(ptr, sl);
+                    crc = __shfl(crc, sl);
+                    bl0 = __shfl(bl0, sl);
+                    if constexpr ((K & 4) == 0) a3 = __shfl(a3, sl);  // still to be read by g2
+                    if constexpr ((K & 2) == 0) a2 = __shfl(a2, sl);  // ... by g1
+                    if constexpr ((K & 1) == 0) a1 = __shfl(a1, sl);  // ... by g0
+                    if (refilled) { bit = 1; PM = c1s; }
+                    else if (s0) { bit = 0; PM = c0; }
+                    else if (s1) { bit = 1; PM = c1; }
+                    else { bit = 0; PM = c0; }  // tie rule: un-refilled dead slot continues as its 0-branch
+                }
+            }
+            if (CRC_ON) crc ^= bit ? crcw : 0u;
+        }
+        set_bit_k<K>(o, bit);
+    }
+
+    // ---- the 8 leaves of octet o; a3 holds the level-3 LLRs ----
+    __device__ __forceinline__ void octet(int o, uint32_t fm)
+    {
+        // leaf 0: f2 f1 f0
+        a2 = chk(a3, shl_lanes<4>(a3));
+        a1 = chk(a2, shl_lanes<2>(a2));
+        decide<0>(o, fm & 1, chk(a1, shl_lanes<1>(a1)));
+        // leaf 1: g0
+        decide<1>(o, (fm >> 1) & 1, g_bit<R>(a1, shl_lanes<1>(a1), bl0, 1));
+        // leaf 2: g1 f0
+        a1 = g_bit<R>(a2, shl_lanes<2>(a2), bl0, 2 + pos);
+        decide<2>(o, (fm >> 2) & 1, chk(a1, shl_lanes<1>(a1)));
+        // leaf 3: g0
+        decide<3>(o, (fm >> 3) & 1, g_bit<R>(a1, shl_lanes<1>(a1), bl0, 1));
+        // leaf 4: g2 f1 f0
+        a2 = g_bit<R>(a3, shl_lanes<4>(a3), bl0, 4 + pos);
+        a1 = chk(a2, shl_lanes<2>(a2));
+        decide<4>(o, (fm >> 4) & 1, chk(a1, shl_lanes<1>(a1)));
+        // leaf 5: g0
+        decide<5>(o, (fm >> 5) & 1, g_bit<R>(a1, shl_lanes<1>(a1), bl0, 1));
+        // leaf 6: g1 f0
+        a1 = g_bit<R>(a2, shl_lanes<2>(a2), bl0, 2 + pos);
+        decide<6>(o, (fm >> 6) & 1, chk(a1, shl_lanes<1>(a1)));
+        // leaf 7: g0
+        decide<7>(o, (fm >> 7) & 1, g_bit<R>(a1, shl_lanes<1>(a1), bl0, 1));
+    }
+};
+
+template <typename R, typename IN, int NLOG, bool CRC_ON>
+__global__ __launch_bounds__(256, 2) void k_scl_fast(SclParams P)
+{
+    using D = FastDec<R, NLOG, CRC_ON>;
+    using C = FastCfg<R, NLOG>;
+    constexpr int N = C::N, NW = C::NW, L = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = threadIdx.x >> 6;
+    unsigned char *base = smem + C::shared_bytes + (size_t)wave * C::per_wave;
+    uint32_t *frz = reinterpret_cast<uint32_t *>(smem + C::off_frz);
+    uint32_t *crct = reinterpret_cast<uint32_t *>(smem + C::off_crc);
+
+    // block-shared tables
+    Lut<R>::build(smem + C::off_lut, threadIdx.x, blockDim.x);
+    for (int i = threadIdx.x; i < NW; i += blockDim.x) frz[i] = P.frozen[i];
+    if (CRC_ON)
+        for (int i = threadIdx.x; i < N; i += blockDim.x) crct[i] = P.crc_tab[i];
+    __syncthreads();
+
+    D s;
+    s.lane = threadIdx.x & 63;
+    s.p = s.lane >> 3;
+    s.pos = s.lane & 7;
+    s.lut.bind(smem + C::off_lut);
+    s.crct = crct;
+    s.ch = reinterpret_cast<R *>(base + C::off_ch);
+    s.tl = reinterpret_cast<R *>(base + C::off_tl);
+    s.blw = reinterpret_cast<uint32_t *>(base + C::off_bl);
+    s.curw = reinterpret_cast<uint32_t *>(base + C::off_cw);
+    s.cand = reinterpret_cast<R *>(base + C::off_cd);
+    s.keys = reinterpret_cast<uint32_t *>(base + C::off_ky);
+    {   // rank network addressing: candidate i = lane & 15 is (slot i & 7, branch i >> 3), stored at keys[2*slot + branch]
+        const int i = s.lane & 15, r = s.lane >> 4;
+        const int jj = (i + 4 * r) & 15;
+        s.own_addr = 4 * (2 * (i & 7) + (i >> 3));
+        s.oth_addr = 4 * (2 * (jj & 7) + (jj >> 3));
+    }
+    const int lane = s.lane, p = s.p, pos = s.pos;
+    const int wave_global = blockIdx.x * C::WAVES + wave;
+    const int waves_total = gridDim.x * C::WAVES;
+
+    for (int frame = wave_global; frame < P.B; frame += waves_total) {
+        // ---- channel LLRs (SCL_1024.c:574-578) ----
+        {
+            const IN *src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
+#pragma unroll 4
+            for (int i = lane; i < N; i += 64) {
+                double v = (double)src[i];
+                if (P.sigma > 0) v = llr_from_y(v, P.sigma);
+                s.ch[i] = (R)v;
+            }
+        }
+        lds_fence();
+        // root f, single path: the left child of the root is shared by every path (computed before any fork)
+#pragma unroll 2
+        for (int e = lane; e < N / 2; e += 64) s.tl[e] = s.chk(s.ch[e], s.ch[e + N / 2]);
+        // the top-level steps read beta words that the first half of the tree has not written yet: keep them defined
+        for (int w = lane; w < 8 * NW; w += 64) s.blw[w] = 0;
+        lds_fence();
+
+        s.PM = R(0);
+        s.ptr = 0;
+        for (int t = 4; t <= C::HI; ++t) s.set_pa(t, p);
+        for (int t = 5; t <= C::TOP; ++t) s.set_pb(t, p);
+        s.crc = 0;
+        s.bl0 = 0;
+        s.a1 = s.a2 = s.a3 = R(0);
+        s.fl = 0;
+        s.logact = 0;
+        uint32_t fword = 0;
+
+        for (int o = 0; o < N / 8; ++o) {
+            if ((o & 3) == 0) fword = frz[o >> 2];
+            s.octet_head(o);
+            s.octet(o, (fword >> (8 * (o & 3))) & 0xFFu);
+        }
+
+        // ================= choose the path (SCL_1024.c:667-674; CASCL_1024_L8.c:725-755) =================
+        const bool pass = CRC_ON && (s.crc == 0);
+        const bool any = __ballot(pass && pos == 0) != 0ull;
+        int best = -1;
+        R best_pm = R(0);
+        for (int q = 0; q < L; ++q) {
+            const R pq = __shfl(s.PM, q * 8);
+            const int okq = __shfl((int)(any ? pass : true), q * 8);
+            if (okq && (best < 0 || pq < best_pm)) {
+                best = q;
+                best_pm = pq;
+            }
+        }
+        uint32_t fl = s.fl;
+        if (any) fl |= 0x2u;
+        // x_hat = root partial sums of the winner (curw after the last leaf); u_hat = x_hat F^{(x)n}
+        lds_fence();
+        uint32_t *xw = s.curw + (size_t)best * NW;
+        {
+            uint32_t x = xw[lane & (NW - 1)];
+            x ^= (x >> 1) & 0x55555555u;
+            x ^= (x >> 2) & 0x33333333u;
+            x ^= (x >> 4) & 0x0F0F0F0Fu;
+            x ^= (x >> 8) & 0x00FF00FFu;
+            x ^= (x >> 16) & 0x0000FFFFu;
+#pragma unroll
+            for (int hw = 1; hw < NW; hw <<= 1) {
+                const uint32_t o = __shfl_down(x, hw);
+                if (!(lane & hw)) x ^= o;
+            }
+            if (lane < NW) P.out_bits[(size_t)frame * NW + lane] = x;
+        }
+        if (lane == 0) {
+            if (P.pm) P.pm[frame] = (double)best_pm;
+            if (P.flags) P.flags[frame] = fl;
+        }
+        lds_fence();
+    }
+}
+
+}  // namespace polar
