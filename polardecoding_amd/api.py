@@ -34,7 +34,8 @@ class _Cfg(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libpolar_hip.so")
+    # POLAR_HIP_LIB: developer override (timing experiments with instrumented builds of the same library)
+    return os.environ.get("POLAR_HIP_LIB") or os.path.join(_HERE, "lib", "libpolar_hip.so")
 
 
 _lib = None

@@ -62,6 +62,31 @@ __device__ __forceinline__ float shr_lanes(float x)
     return __int_as_float(dpp_i<0x110 + K>(__float_as_int(x)));
 }
 
+// lane i <- lane i^4 (inside an 8-lane path group): row_shl:4 into the low quads, row_shr:4 into the high quads
+__device__ __forceinline__ int xor4_i(int v)
+{
+    int t = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);
+    return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);
+}
+template <int QP>  // quad_perm
+__device__ __forceinline__ int quad_i(int v) { return __builtin_amdgcn_update_dpp(0, v, QP, 0xF, 0xF, true); }
+__device__ __forceinline__ double xor_lanes4(double x)
+{
+    long long b = __double_as_longlong(x);
+    int lo = xor4_i((int)b), hi = xor4_i((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ float xor_lanes4(float x) { return __int_as_float(xor4_i(__float_as_int(x))); }
+template <int QP>
+__device__ __forceinline__ double quad_lanes(double x)
+{
+    long long b = __double_as_longlong(x);
+    int lo = quad_i<QP>((int)b), hi = quad_i<QP>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int QP>
+__device__ __forceinline__ float quad_lanes(float x) { return __int_as_float(quad_i<QP>(__float_as_int(x))); }
+
 __device__ __forceinline__ void lds_fence() { __asm__ volatile("" ::: "memory"); }
 
 // ---- table-driven staircase -----------------------------------------------------------------------
@@ -159,6 +184,15 @@ __device__ __forceinline__ float minabs(float a, float b) { return __builtin_fmi
 template <typename R>
 __device__ __forceinline__ R chk_lut(R a, R b, const Lut<R> &L)
 {
+#ifdef POLAR_DOUBLE_CHK  // timing experiment: marginal cost of one more CHK
+    {
+        const R s2 = b + a * R(1.0000001), d2 = a - b * R(1.0000001);
+        const int is2 = L.idx(s2), id2 = L.idx(d2);
+        const R delta2 = L.dlt[is2 * 8 + id2];
+        const R r2 = xor_sign(minabs(s2, d2), a, b) + delta2;
+        __asm__ volatile("" ::"v"(r2));
+    }
+#endif
     const R s = a + b, d = a - b;
     const int is = L.idx(s), id = L.idx(d);
     const R delta = L.dlt[is * 8 + id];
@@ -453,6 +487,12 @@ struct FastDec {
         if (CRC_ON && !frozen) crcw = crct[j];
         uint32_t bit = 0;
         const R absl = absr(lam);
+#ifdef POLAR_DOUBLE_PHI
+        {
+            const R t2 = lut.tabv(lam * R(1.0000001));
+            __asm__ volatile("" ::"v"(t2));
+        }
+#endif
         const R tt = lut.tabv(lam);
         const R pen = tt + absl;
         const R ph0 = (lam < R(0)) ? pen : tt;  // PHI(.,0)  (SCL_1024.c:481-502)
@@ -469,6 +509,12 @@ struct FastDec {
             } else {
                 // phase 2 (SCL_1024.c:610-661)
                 const R c0 = PM + ph0, c1 = PM + ph1;
+#ifdef POLAR_DOUBLE_RANK
+                {
+                    const uint32_t m2 = survivors(c1, c0);
+                    __asm__ volatile("" ::"s"(m2));
+                }
+#endif
                 const uint32_t mask = survivors(c0, c1);
                 const uint32_t m0 = mask & 0xFFu, m1 = mask >> 8;
                 const uint32_t m_both = m0 & m1, m_dead = ~(m0 | m1) & 0xFFu;
@@ -513,6 +559,41 @@ struct FastDec {
             if (CRC_ON) crc ^= bit ? crcw : 0u;
         }
         set_bit_k<K>(o, bit);
+    }
+
+    // ---- octets whose first seven leaves are frozen (patterns 0xFF, 0x7F) ----
+    // All partner bits inside the octet are 0, so every g is cL + cU and the three levels can be evaluated
+    // breadth-first: one CHK pass per level produces the f results in the low half and the g results in the
+    // high half of each node -- the same operations on the same operands as the leaf-by-leaf schedule.
+    // lambda_k ends in lane pos = k.  The frozen-leaf metric updates PM += PHI(lambda_k, 0) keep leaf order.
+    __device__ __forceinline__ void octet_frozen_prefix(int o, bool last_frozen)
+    {
+        R x = a3, y = xor_lanes4(x);
+        R f = chk(x, y), g = x + y;
+        x = (pos & 4) ? g : f;
+        y = quad_lanes<0x4E>(x);  // quad_perm [2,3,0,1]: lane ^ 2
+        f = chk(x, y); g = x + y;
+        x = (pos & 2) ? g : f;
+        y = quad_lanes<0xB1>(x);  // quad_perm [1,0,3,2]: lane ^ 1
+        f = chk(x, y); g = x + y;
+        const R lam = (pos & 1) ? g : f;
+        const R absl = absr(lam);
+        const R tt = lut.tabv(lam);
+        R ph = (lam < R(0)) ? tt + absl : tt;  // PHI(lambda_k, 0) in lane k
+        PM += ph;
+        ph = shl_lanes<1>(ph); PM += ph;
+        ph = shl_lanes<1>(ph); PM += ph;
+        ph = shl_lanes<1>(ph); PM += ph;
+        ph = shl_lanes<1>(ph); PM += ph;
+        ph = shl_lanes<1>(ph); PM += ph;
+        ph = shl_lanes<1>(ph); PM += ph;
+        bl0 &= ~0xFEu;  // partial sums of levels 0..2 inside this octet: all zero
+        if (last_frozen) {
+            ph = shl_lanes<1>(ph); PM += ph;
+            set_bit_tail(8 * o + 7, 0u);
+        } else {
+            decide<7>(o, false, shl_lanes<7>(lam));
+        }
     }
 
     // ---- the 8 leaves of octet o; a3 holds the level-3 LLRs ----
@@ -617,7 +698,9 @@ __global__ __launch_bounds__(256, 2) void k_scl_fast(SclParams P)
         for (int o = 0; o < N / 8; ++o) {
             if ((o & 3) == 0) fword = frz[o >> 2];
             s.octet_head(o);
-            s.octet(o, (fword >> (8 * (o & 3))) & 0xFFu);
+            const uint32_t fm = (fword >> (8 * (o & 3))) & 0xFFu;
+            if ((fm & 0x7Fu) == 0x7Fu) s.octet_frozen_prefix(o, fm == 0xFFu);
+            else s.octet(o, fm);
         }
 
         // ================= choose the path (SCL_1024.c:667-674; CASCL_1024_L8.c:725-755) =================
