@@ -45,6 +45,7 @@ struct polar_ctx {
     bool own_stream = false;
     int num_cu = 0;
     Buf in, bits, pm, flags;              // staging for the host-pointer entry points
+    Buf scratch;                          // k_scl_fast per-wave scratch
     std::string last_error;
     std::string kernel_name;
     bool force_generic = false;
@@ -171,7 +172,14 @@ int launch_fast(polar_ctx *c, const polar::SclParams &P)
     long long blocks_needed = ((long long)P.B + WAVES - 1) / WAVES;
     int grid = (int)std::min<long long>(blocks_needed, (long long)occ * c->num_cu);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, c->stream, P);
+    polar::SclParams Q = P;
+    const size_t sc_bytes = polar::FastCfg<R, NLOG>::scratch_elems * sizeof(R) * (size_t)grid * WAVES;
+    if (sc_bytes) {
+        int rc = ensure(c, c->scratch, sc_bytes);
+        if (rc) return rc;
+        Q.scratch = c->scratch.p;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
     return POLAR_OK;
 }
@@ -236,6 +244,26 @@ int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sig
     P.crc_tab = (g.algo == POLAR_ALGO_CASCL) ? c->d_crc_tab : nullptr;
     P.N = g.N; P.n = c->n; P.B = (int)B;
     P.sc_mode = (g.algo == POLAR_ALGO_SC) ? 1 : 0;
+    P.dbg = nullptr;
+    P.scratch = nullptr;
+#ifdef POLAR_STAMPS
+    static unsigned long long *s_dbg = nullptr;
+    if (!s_dbg) {
+        (void)hipMalloc(&s_dbg, 8 * sizeof(unsigned long long));
+        (void)hipMemset(s_dbg, 0, 8 * sizeof(unsigned long long));
+        atexit([] {
+            unsigned long long h[8];
+            (void)hipMemcpy(h, s_dbg, sizeof h, hipMemcpyDeviceToHost);
+            const char *nm[8] = {"prologue", "load ch", "tl+init", "octet_head", "octet frozen-prefix", "octet generic",
+                                 "select+store", "-"};
+            unsigned long long tot = 0;
+            for (int i = 0; i < 8; ++i) tot += h[i];
+            for (int i = 0; i < 7; ++i)
+                fprintf(stderr, "[stamps] %-22s %14llu ticks  %5.1f %%\n", nm[i], h[i], 100.0 * h[i] / (tot ? tot : 1));
+        });
+    }
+    P.dbg = s_dbg;
+#endif
     if (fast_ok(c, in_is_f32)) {
         const bool crc = g.algo == POLAR_ALGO_CASCL;
         if (!f32) return launch_fast_n<double, double>(c, P, crc);
@@ -412,7 +440,7 @@ void polar_destroy(polar_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (Buf *b : {&c->in, &c->bits, &c->pm, &c->flags})
+    for (Buf *b : {&c->in, &c->bits, &c->pm, &c->flags, &c->scratch})
         if (b->p) (void)hipFree(b->p);
     if (c->d_frozen) (void)hipFree(c->d_frozen);
     if (c->d_info) (void)hipFree(c->d_info);

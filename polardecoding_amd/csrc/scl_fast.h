@@ -214,9 +214,21 @@ struct FastCfg {
     static constexpr int N = 1 << NLOG;
     static constexpr int NW = N / 32;
     static constexpr int TOP = NLOG - 1;      // virtual level (never stored per path)
-    static constexpr int HI = NLOG - 2;       // highest register level
-    static constexpr int NA = (1 << HI) / 4;  // registers for levels 4..HI (level t at offset 2^t/8)
+    static constexpr int HI = NLOG - 2;       // highest stored level
+    // BIG (N = 1024): levels 7 and 8, the top-left level and the channel vector stay OUT of registers and LDS
+    // (per-wave scratch in global memory, L2/MALL resident; the channel LLRs are re-read from the input), so
+    // that four waves per SIMD fit.  Registers then hold levels 4..6 only.
+    static constexpr bool BIG = NLOG >= 10;
+    static constexpr int RHI = BIG ? 6 : HI;  // highest REGISTER level
+    static constexpr int NA = (1 << RHI) / 4; // registers for levels 4..RHI (level t at offset 2^t/8)
     static constexpr int WAVES = 4;
+    static constexpr int MIN_WAVES_PER_SIMD = BIG ? 4 : 4;
+    // per-wave global scratch (elements of R): l8 [8][256], l7 [8][128], l6 staging [8][64], top-left [512]
+    static constexpr size_t sc_l8 = 0;
+    static constexpr size_t sc_l7 = sc_l8 + 8 * 256;
+    static constexpr size_t sc_l6 = sc_l7 + 8 * 128;
+    static constexpr size_t sc_tl = sc_l6 + 8 * 64;
+    static constexpr size_t scratch_elems = BIG ? sc_tl + 512 : 0;
     // block-shared LDS
     static constexpr size_t off_lut = 0;
     static constexpr size_t off_frz = off_lut + ((Lut<R>::bytes + 15) / 16) * 16;   // frozen words [NW]
@@ -224,28 +236,35 @@ struct FastCfg {
     static constexpr size_t shared_bytes = off_crc + 4 * N;
     // per-wave LDS
     static constexpr size_t off_ch = 0;
-    static constexpr size_t off_tl = off_ch + sizeof(R) * N;        // top-left level (N/2)
-    static constexpr size_t off_bl = off_tl + sizeof(R) * (N / 2);  // saved partial sums [8][NW]
-    static constexpr size_t off_cw = off_bl + 4 * 8 * NW;           // working partial sums [8][NW]
+    static constexpr size_t off_tl = off_ch + (BIG ? 0 : sizeof(R) * N);        // (small N) channel LLRs
+    static constexpr size_t off_bl = off_tl + (BIG ? 0 : sizeof(R) * (N / 2));  // (small N) top-left level
+    static constexpr size_t off_cw = off_bl + 4 * 8 * NW;           // saved partial sums [8][NW], then working [8][NW]
     static constexpr size_t off_cd = off_cw + 4 * 8 * NW;           // candidates [16] (exact fall-back)
     static constexpr size_t off_ky = off_cd + sizeof(R) * 16;       // candidate keys [16] u32
     static constexpr size_t per_wave = off_ky + 64;
     static constexpr size_t total = shared_bytes + WAVES * per_wave;
 };
 
+// scratch traffic: plain stores (write-through to L2), loads that bypass the per-CU L1 (relaxed agent-scope
+// atomic load = global_load ... sc1) so that a line cached from an earlier frame can never be returned
+__device__ __forceinline__ double ld_sc(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void vm_drain() { __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // 32-bit ordering key of a non-negative metric: f32 bits are exact, the high word of an f64 is exact
 // unless two candidates share it across the survivor boundary (then the exact fall-back runs)
 __device__ __forceinline__ uint32_t metric_key(double x) { return (uint32_t)__double2hiint(x); }
 __device__ __forceinline__ uint32_t metric_key(float x) { return (uint32_t)__float_as_int(x); }
 
-template <typename R, int NLOG, bool CRC_ON>
+template <typename R, typename IN, int NLOG, bool CRC_ON>
 struct FastDec {
     using C = FastCfg<R, NLOG>;
-    static constexpr int N = C::N, NW = C::NW, TOP = C::TOP, HI = C::HI, L = 8;
+    static constexpr int N = C::N, NW = C::NW, TOP = C::TOP, HI = C::HI, RHI = C::RHI, L = 8;
+    static constexpr bool BIG = C::BIG;
     static constexpr int NFA = HI - 3;  // pointer fields for LLR levels 4..HI; partial-sum levels 5..TOP follow
 
     // ---- per-lane state ----
-    R A[C::NA];      // levels 4..HI
+    R A[C::NA];      // levels 4..RHI
     R a3, a2, a1;    // levels 3..1 (element pos)
     R PM;            // valid at pos 0
     uint32_t ptr;    // 3 bits per field: LLR level t -> field t-4; partial sums of level t -> field NFA + t-5
@@ -259,6 +278,18 @@ struct FastDec {
     R *ch, *tl, *cand;
     uint32_t *blw, *curw, *keys;
     const uint32_t *crct;
+    // global
+    R *scr;          // per-wave scratch (BIG)
+    const IN *src;   // this frame's input row
+    double sigma;
+
+    // channel LLR straight from the input (SCL_1024.c:574-578)
+    __device__ __forceinline__ R chv(int e) const
+    {
+        double v = (double)src[e];
+        if (sigma > 0) v = llr_from_y(v, sigma);
+        return (R)v;
+    }
 
     __device__ __forceinline__ int pa(int t) const { return (ptr >> (3 * (t - 4))) & 7; }
     __device__ __forceinline__ void set_pa(int t, int v) { ptr = (ptr & ~(7u << (3 * (t - 4)))) | ((uint32_t)v << (3 * (t - 4))); }
@@ -306,6 +337,7 @@ struct FastDec {
         set_pa(T, p);
     }
 
+    // ======================= small N: levels up to HI in registers, ch / top-left in LDS =======================
     // Level HI from the top level.  right: j >= N/2 (virtual top level from ch and beta_TOP), else the stored
     // top-left array.  gstep: g (with beta_HI) instead of f.  The level-HI registers are rotated so that the
     // body exists once in the code.
@@ -344,6 +376,96 @@ struct FastDec {
         set_pa(HI, p);
     }
 
+    // ======================= N = 1024: levels 8, 7 and the top-left level in the per-wave scratch =======================
+    __device__ __forceinline__ R *l8(int slot) const { return scr + C::sc_l8 + slot * 256; }
+    __device__ __forceinline__ R *l7(int slot) const { return scr + C::sc_l7 + slot * 128; }
+    __device__ __forceinline__ R *l6s(int slot) const { return scr + C::sc_l6 + slot * 64; }
+    __device__ __forceinline__ R *tls() const { return scr + C::sc_tl; }
+
+    __device__ __forceinline__ void load_l6()
+    {
+        vm_drain();
+        const R *q = l6s(p) + pos;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) A[8 + r] = ld_sc(q + 8 * r);
+        set_pa(6, p);
+    }
+    // Octet heads with d >= 8 (j = 0, 256, 512, 768): level 8 from the top level (f or g), then f to 7 and 6.
+    // Per pass rr the lane produces its level-8 elements e = pos + 8 rr + 64 k (k < 4), the two level-7 and the
+    // one level-6 element below them, so no value is re-read before it is complete.
+    __device__ __forceinline__ void from_top(bool right, bool gstep)
+    {
+        vm_drain();
+        const uint32_t *bt = blw + pb(TOP) * NW + (1 << (TOP - 5));  // beta_9: 16 words
+        const uint32_t *bh = blw + pb(HI) * NW + (1 << (HI - 5));    // beta_8: 8 words
+        const R *t = tls();
+        R *o8 = l8(p), *o7 = l7(p), *o6 = l6s(p);
+        for (int rr = 0; rr < 8; ++rr) {
+            const int e0 = pos + 8 * rr;
+            const int sh = 8 * (rr & 3);
+            const int wq = rr >> 2;
+            R v8[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + 64 * k;
+                R x, y;
+                if (right) {
+                    const uint32_t w0 = bt[2 * k + wq] >> pos, w1 = bt[8 + 2 * k + wq] >> pos;
+                    x = g_bit<R>(chv(e), chv(e + 512), w0, sh);
+                    y = g_bit<R>(chv(e + 256), chv(e + 768), w1, sh);
+                } else {
+                    x = ld_sc(t + e);
+                    y = ld_sc(t + e + 256);
+                }
+                if (gstep) v8[k] = g_bit<R>(x, y, bh[2 * k + wq] >> pos, sh);
+                else v8[k] = chk(x, y);
+                o8[e] = v8[k];
+            }
+            const R v70 = chk(v8[0], v8[2]), v71 = chk(v8[1], v8[3]);
+            o7[e0] = v70;
+            o7[e0 + 64] = v71;
+            o6[e0] = chk(v70, v71);
+        }
+        set_pa(8, p);
+        set_pa(7, p);
+        load_l6();
+    }
+    // d == 7 (j = 128 * odd): g to level 7 from the owner's level 8, then f to level 6
+    __device__ __forceinline__ void from_l8()
+    {
+        vm_drain();
+        const R *s8 = l8(pa(8));
+        const uint32_t *b7 = blw + pb(7) * NW + (1 << (7 - 5));  // beta_7: 4 words
+        R *o7 = l7(p), *o6 = l6s(p);
+        for (int rr = 0; rr < 8; ++rr) {
+            const int e0 = pos + 8 * rr;
+            const int sh = 8 * (rr & 3);
+            const int wq = rr >> 2;
+            const R a0 = ld_sc(s8 + e0), a1_ = ld_sc(s8 + e0 + 64), a2_ = ld_sc(s8 + e0 + 128), a3_ = ld_sc(s8 + e0 + 192);
+            const R v70 = g_bit<R>(a0, a2_, b7[wq] >> pos, sh);
+            const R v71 = g_bit<R>(a1_, a3_, b7[2 + wq] >> pos, sh);
+            o7[e0] = v70;
+            o7[e0 + 64] = v71;
+            o6[e0] = chk(v70, v71);
+        }
+        set_pa(7, p);
+        load_l6();
+    }
+    // d == 6 (j = 64 * odd): g to level 6 (registers) from the owner's level 7
+    __device__ __forceinline__ void from_l7()
+    {
+        vm_drain();
+        const R *s7 = l7(pa(7)) + pos;
+        const uint32_t *b6 = blw + pb(6) * NW + (1 << (6 - 5));  // beta_6: 2 words
+        const uint32_t w0 = b6[0] >> pos, w1 = b6[1] >> pos;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const R x = ld_sc(s7 + 8 * r), y = ld_sc(s7 + 8 * r + 64);
+            A[8 + r] = g_bit<R>(x, y, r < 4 ? w0 : w1, 8 * (r & 3));
+        }
+        set_pa(6, p);
+    }
+
     template <int T>
     __device__ __forceinline__ void f_chain_up(int d)
     {
@@ -365,15 +487,27 @@ struct FastDec {
     __device__ __forceinline__ void octet_head(int o)
     {
         const int d = (o == 0) ? NLOG : 3 + __builtin_ctz((unsigned)o);
-        if (d >= HI) {
-            top_to_hi(/*right=*/o >= N / 16, /*gstep=*/d == HI);
-        } else if (d >= 4) {
-            g_select<HI - 1>(d);
+        if constexpr (BIG) {
+            if (d >= 8) from_top(/*right=*/o >= N / 16, /*gstep=*/d == 8);
+            else if (d == 7) from_l8();
+            else if (d == 6) from_l7();
+            else if (d >= 4) g_select<5>(d);
+            else {
+                const int sl = pa(4) * 8 + pos;
+                a3 = g_bit<R>(__shfl(A[2], sl), __shfl(A[3], sl), bl0, 8 + pos);
+            }
+            f_chain_up<5>(d);
         } else {
-            const int sl = pa(4) * 8 + pos;
-            a3 = g_bit<R>(__shfl(A[2], sl), __shfl(A[3], sl), bl0, 8 + pos);
+            if (d >= HI) {
+                top_to_hi(/*right=*/o >= N / 16, /*gstep=*/d == HI);
+            } else if (d >= 4) {
+                g_select<HI - 1>(d);
+            } else {
+                const int sl = pa(4) * 8 + pos;
+                a3 = g_bit<R>(__shfl(A[2], sl), __shfl(A[3], sl), bl0, 8 + pos);
+            }
+            f_chain_up<HI - 1>(d);
         }
-        f_chain_up<HI - 1>(d);
         if (d > 3) a3 = chk(A[2], A[3]);
     }
 
@@ -624,10 +758,20 @@ struct FastDec {
     }
 };
 
+#ifdef POLAR_STAMPS  // diagnostic build: s_memtime per section, summed per wave, added to P.dbg[]
+#define STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsec[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 template <typename R, typename IN, int NLOG, bool CRC_ON>
-__global__ __launch_bounds__(256, 2) void k_scl_fast(SclParams P)
+__global__ __launch_bounds__(256, (FastCfg<R, NLOG>::MIN_WAVES_PER_SIMD)) void k_scl_fast(SclParams P)
 {
-    using D = FastDec<R, NLOG, CRC_ON>;
+#ifdef POLAR_STAMPS
+    unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+    using D = FastDec<R, IN, NLOG, CRC_ON>;
     using C = FastCfg<R, NLOG>;
     constexpr int N = C::N, NW = C::NW, L = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -651,6 +795,7 @@ __global__ __launch_bounds__(256, 2) void k_scl_fast(SclParams P)
     s.crct = crct;
     s.ch = reinterpret_cast<R *>(base + C::off_ch);
     s.tl = reinterpret_cast<R *>(base + C::off_tl);
+    s.sigma = P.sigma;
     s.blw = reinterpret_cast<uint32_t *>(base + C::off_bl);
     s.curw = reinterpret_cast<uint32_t *>(base + C::off_cw);
     s.cand = reinterpret_cast<R *>(base + C::off_cd);
@@ -665,21 +810,25 @@ __global__ __launch_bounds__(256, 2) void k_scl_fast(SclParams P)
     const int wave_global = blockIdx.x * C::WAVES + wave;
     const int waves_total = gridDim.x * C::WAVES;
 
+    STAMP(0);
     for (int frame = wave_global; frame < P.B; frame += waves_total) {
-        // ---- channel LLRs (SCL_1024.c:574-578) ----
-        {
-            const IN *src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
-#pragma unroll 4
-            for (int i = lane; i < N; i += 64) {
-                double v = (double)src[i];
-                if (P.sigma > 0) v = llr_from_y(v, P.sigma);
-                s.ch[i] = (R)v;
-            }
-        }
-        lds_fence();
-        // root f, single path: the left child of the root is shared by every path (computed before any fork)
+        s.src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
+        if constexpr (C::BIG) {
+            // root f, single path: the left child of the root is shared by every path (computed before any fork)
+            s.scr = reinterpret_cast<R *>(P.scratch) + (size_t)wave_global * C::scratch_elems;
+            R *t = s.tls();
+            STAMP(1);
 #pragma unroll 2
-        for (int e = lane; e < N / 2; e += 64) s.tl[e] = s.chk(s.ch[e], s.ch[e + N / 2]);
+            for (int e = lane; e < N / 2; e += 64) t[e] = s.chk(s.chv(e), s.chv(e + N / 2));
+        } else {
+            // ---- channel LLRs (SCL_1024.c:574-578) ----
+#pragma unroll 4
+            for (int i = lane; i < N; i += 64) s.ch[i] = s.chv(i);
+            lds_fence();
+            STAMP(1);
+#pragma unroll 2
+            for (int e = lane; e < N / 2; e += 64) s.tl[e] = s.chk(s.ch[e], s.ch[e + N / 2]);
+        }
         // the top-level steps read beta words that the first half of the tree has not written yet: keep them defined
         for (int w = lane; w < 8 * NW; w += 64) s.blw[w] = 0;
         lds_fence();
@@ -694,13 +843,15 @@ __global__ __launch_bounds__(256, 2) void k_scl_fast(SclParams P)
         s.fl = 0;
         s.logact = 0;
         uint32_t fword = 0;
+        STAMP(2);
 
         for (int o = 0; o < N / 8; ++o) {
             if ((o & 3) == 0) fword = frz[o >> 2];
             s.octet_head(o);
+            STAMP(3);
             const uint32_t fm = (fword >> (8 * (o & 3))) & 0xFFu;
-            if ((fm & 0x7Fu) == 0x7Fu) s.octet_frozen_prefix(o, fm == 0xFFu);
-            else s.octet(o, fm);
+            if ((fm & 0x7Fu) == 0x7Fu) { s.octet_frozen_prefix(o, fm == 0xFFu); STAMP(4); }
+            else { s.octet(o, fm); STAMP(5); }
         }
 
         // ================= choose the path (SCL_1024.c:667-674; CASCL_1024_L8.c:725-755) =================
@@ -740,7 +891,12 @@ __global__ __launch_bounds__(256, 2) void k_scl_fast(SclParams P)
             if (P.flags) P.flags[frame] = fl;
         }
         lds_fence();
+        STAMP(6);
     }
+#ifdef POLAR_STAMPS
+    if (P.dbg && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&P.dbg[i], tsec[i]);
+#endif
 }
 
 }  // namespace polar

@@ -34,6 +34,8 @@ struct SclParams {
     int N, n;
     int B;
     int sc_mode;               // 1: plain SC decisions (SCdecode), L must be 1
+    void *scratch;             // k_scl_fast, N = 1024: per-wave global scratch (FastCfg::scratch_elems each)
+    unsigned long long *dbg;   // diagnostic builds only (-DPOLAR_STAMPS): per-section cycle sums
 };
 
 template <int LOGL>
