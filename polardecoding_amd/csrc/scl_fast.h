@@ -87,96 +87,143 @@ __device__ __forceinline__ double quad_lanes(double x)
 template <int QP>
 __device__ __forceinline__ float quad_lanes(float x) { return __int_as_float(quad_i<QP>(__float_as_int(x))); }
 
+// max(x, 0) (x = +-lambda): the metric penalty |lambda| or 0, one instruction
+__device__ __forceinline__ double posmax(double x)
+{
+    double m;
+    __asm__("v_max_f64 %0, %1, 0" : "=v"(m) : "v"(x));
+    return m;
+}
+__device__ __forceinline__ float posmax(float x)
+{
+    float m;
+    __asm__("v_max_f32_e64 %0, %1, 0" : "=v"(m) : "v"(x));
+    return m;
+}
+
 __device__ __forceinline__ void lds_fence() { __asm__ volatile("" ::: "memory"); }
 
 // ---- table-driven staircase -----------------------------------------------------------------------
 // cell(x) for x >= 0: 0 for x < 0.125, 1..48 = 8 cells per binade over [0.125, 8), 49 for x >= 8.
-// The seven thresholds 0.196 .. 4.5 (SCL_1024.c:352-358) fall into seven different cells.
+// The seven thresholds 0.196 .. 4.5 (SCL_1024.c:352-358) fall into seven different cells, so ONE exact
+// compare against the cell's threshold finishes the 8-level look-up.
+// LDS entry (48 bytes): [thr | s_lo s_hi] [thr | d_lo d_hi] [T_lo T_hi], where s_*/d_* are the byte offsets
+// of the row / column of the 8x8 table of differences for "below thr" / "at or above thr".
 template <typename R>
 struct Cell;
 template <>
 struct Cell<double> {
-    struct __attribute__((aligned(16))) Entry { double thr; int base; int pad; double tlo, thi; };
-    static __device__ __forceinline__ int of(double x)
-    {
-        const int t = ((__double2hiint(x) & 0x7fffffff) - 0x3FC00000) >> 17;
-        return min(max(t, -1), 48) + 1;
-    }
+    static constexpr int BIAS = 0x3FC00000 >> 17;  // cell number of 0.125
+    static __device__ __forceinline__ int raw(double x) { return (int)__builtin_amdgcn_ubfe((unsigned)__double2hiint(x), 17, 14); }
 };
 template <>
 struct Cell<float> {
-    struct __attribute__((aligned(16))) Entry { float thr; int base; float tlo, thi; };
-    static __device__ __forceinline__ int of(float x)
-    {
-        const int t = ((__float_as_int(x) & 0x7fffffff) - 0x3E000000) >> 20;
-        return min(max(t, -1), 48) + 1;
-    }
+    static constexpr int BIAS = 0x3E000000 >> 20;
+    static __device__ __forceinline__ int raw(float x) { return (int)__builtin_amdgcn_ubfe((unsigned)__float_as_int(x), 20, 11); }
 };
 
 template <typename R>
 struct Lut {
-    using Entry = typename Cell<R>::Entry;
-    static constexpr int NCELL = 50;
-    static constexpr size_t bytes = ((sizeof(Entry) * NCELL + 15) / 16) * 16 + sizeof(R) * 64;
-    const Entry *cells;
-    const R *dlt;  // dlt[i*8+j] = T_i - T_j (one IEEE subtraction, like `delta = T(s); delta -= T(d)`)
+    struct __attribute__((aligned(16))) Q { R thr; int lo, hi; };       // 16 bytes (f32: 12 + tail padding)
+    struct __attribute__((aligned(16))) TP { R lo, hi; };
+    static constexpr int NCELL = 50, STRIDE = 48;
+    static constexpr size_t cell_bytes = (size_t)NCELL * STRIDE;
+    static constexpr size_t bytes = cell_bytes + sizeof(R) * 64;
+    unsigned base;  // LDS byte address of the table, pre-biased: entry(x) = base + clamp(raw(x)) * 48
+    const unsigned char *lds0;  // LDS address 0 as a pointer (keeps the address space known)
+    const R *dlt;   // dlt[i*8+j] = T_i - T_j (one IEEE subtraction, like `delta = T(s); delta -= T(d)`)
 
-    __device__ __forceinline__ void bind(unsigned char *base)
+    static __device__ __forceinline__ int index_of(R x)
     {
-        cells = reinterpret_cast<const Entry *>(base);
-        dlt = reinterpret_cast<const R *>(base + ((sizeof(Entry) * NCELL + 15) / 16) * 16);
+        const int t = Cell<R>::raw(x);
+        return min(max(t, Cell<R>::BIAS - 1), Cell<R>::BIAS + 48) - (Cell<R>::BIAS - 1);
+    }
+    __device__ __forceinline__ void bind(unsigned char *tab)
+    {
+        lds0 = tab;
+        base = (unsigned)(0 - (Cell<R>::BIAS - 1) * STRIDE);
+        __asm__ volatile("" : "+s"(base));  // opaque: keeps the bias inside the multiply-add, offsets in the ds_read
+        dlt = reinterpret_cast<const R *>(tab + cell_bytes);
+    }
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ double thr_of(u4 q, double) { return __hiloint2double((int)q.y, (int)q.x); }
+    static __device__ __forceinline__ float thr_of(u4 q, float) { return __int_as_float((int)q.x); }
+    static __device__ __forceinline__ int lo_of(u4 q, double) { return (int)q.z; }
+    static __device__ __forceinline__ int hi_of(u4 q, double) { return (int)q.w; }
+    static __device__ __forceinline__ int lo_of(u4 q, float) { return (int)q.y; }
+    static __device__ __forceinline__ int hi_of(u4 q, float) { return (int)q.z; }
+    // offset selected by the exact compare |x| >= thr of the 16-byte sub-entry at byte offset `sub`
+    __device__ __forceinline__ int pick(R x, unsigned sub) const
+    {
+        const u4 q = *reinterpret_cast<const u4 *>(lds0 + entry(x) + sub);
+        return (absr(x) >= thr_of(q, R(0))) ? hi_of(q, R(0)) : lo_of(q, R(0));
     }
     // executed by a whole workgroup before its first barrier
-    static __device__ void build(unsigned char *base, int tid, int nthreads)
+    static __device__ void build(unsigned char *tab, int tid, int nthreads)
     {
-        Entry *c = reinterpret_cast<Entry *>(base);
-        R *d = reinterpret_cast<R *>(base + ((sizeof(Entry) * NCELL + 15) / 16) * 16);
+        R *d = reinterpret_cast<R *>(tab + cell_bytes);
         const R thr[7] = {R(0.196), R(0.433), R(0.71), R(1.05), R(1.508), R(2.252), R(4.5)};
         const R tv[8] = {R(0.65), R(0.55), R(0.45), R(0.35), R(0.25), R(0.15), R(0.05), R(0)};
         for (int i = tid; i < NCELL; i += nthreads) {
-            int base_cnt = 0;
+            int b = 0;
             R t = R(__builtin_huge_val());
             for (int k = 0; k < 7; ++k) {
-                const int ck = Cell<R>::of(thr[k]);
-                if (ck < i) ++base_cnt;
+                const int ck = index_of(thr[k]);
+                if (ck < i) ++b;
                 if (ck == i) t = thr[k];
             }
-            c[i].thr = t;
-            c[i].base = base_cnt;
-            c[i].tlo = tv[base_cnt];
-            c[i].thi = tv[base_cnt < 7 ? base_cnt + 1 : 7];
+            const int b1 = b < 7 ? b + 1 : 7;
+            Q *qs = reinterpret_cast<Q *>(tab + i * STRIDE);
+            Q *qd = reinterpret_cast<Q *>(tab + i * STRIDE + 16);
+            TP *tp = reinterpret_cast<TP *>(tab + i * STRIDE + 32);
+            qs->thr = t; qs->lo = b * 8 * (int)sizeof(R); qs->hi = b1 * 8 * (int)sizeof(R);
+            qd->thr = t; qd->lo = b * (int)sizeof(R); qd->hi = b1 * (int)sizeof(R);
+            tp->lo = tv[b]; tp->hi = tv[b1];
         }
         for (int i = tid; i < 64; i += nthreads) d[i] = tv[i >> 3] - tv[i & 7];
     }
-    // number of thresholds <= |x|
-    __device__ __forceinline__ int idx(R x) const
+    // byte offset (from lds0) of the entry of |x|
+    __device__ __forceinline__ unsigned entry(R x) const
     {
-        const Entry *e = cells + Cell<R>::of(x);
-        const R thr = e->thr;
-        const int base = e->base;
-        return base + ((absr(x) >= thr) ? 1 : 0);
+        const int t = Cell<R>::raw(x);
+        const int c = min(max(t, Cell<R>::BIAS - 1), Cell<R>::BIAS + 48);
+        return __umul24((unsigned)c, (unsigned)STRIDE) + base;
     }
     // T(|x|) in one LDS round trip
     __device__ __forceinline__ R tabv(R x) const
     {
-        const Entry *e = cells + Cell<R>::of(x);
-        const R thr = e->thr, lo = e->tlo, hi = e->thi;
-        return (absr(x) >= thr) ? hi : lo;
+        const unsigned e = entry(x);
+        const R thr = *reinterpret_cast<const R *>(lds0 + e);
+        const TP tp = *reinterpret_cast<const TP *>(lds0 + e + 32);
+        return (absr(x) >= thr) ? tp.hi : tp.lo;
     }
 };
 
+// min(|a|, |b|) in one instruction (the generic fmin lowering canonicalises both operands first)
+__device__ __forceinline__ double minabs(double a, double b)
+{
+    double m;
+    __asm__("v_min_f64 %0, |%1|, |%2|" : "=v"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ float minabs(float a, float b)
+{
+    float m;
+    __asm__("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(m) : "v"(a), "v"(b));
+    return m;
+}
+// m >= 0 with the sign of a*b: (m & 0x7fffffff) | ((a ^ b) & 0x80000000) as one v_bfi
 __device__ __forceinline__ double xor_sign(double m, double a, double b)
 {
-    const int s = (__double2hiint(a) ^ __double2hiint(b)) & 0x80000000;
-    return __hiloint2double(__double2hiint(m) ^ s, __double2loint(m));
+    const unsigned x = (unsigned)(__double2hiint(a) ^ __double2hiint(b));
+    const unsigned hi = (x & 0x80000000u) | (unsigned)__double2hiint(m);  // m >= 0: v_and_or_b32
+    return __hiloint2double((int)hi, __double2loint(m));
 }
 __device__ __forceinline__ float xor_sign(float m, float a, float b)
 {
-    const int s = (__float_as_int(a) ^ __float_as_int(b)) & 0x80000000;
-    return __int_as_float(__float_as_int(m) ^ s);
+    const unsigned x = (unsigned)(__float_as_int(a) ^ __float_as_int(b));
+    return __int_as_float((int)((x & 0x80000000u) | (unsigned)__float_as_int(m)));
 }
-__device__ __forceinline__ double minabs(double a, double b) { return __builtin_fmin(__builtin_fabs(a), __builtin_fabs(b)); }
-__device__ __forceinline__ float minabs(float a, float b) { return __builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b)); }
 
 // CHK (SCL_1024.c:343-374) with the staircase taken from the tables.  sign(a)sign(b) is applied by
 // xor of the sign bits: for a = -0.0 the reference uses +1, but then min = 0 and delta = +0, and
@@ -187,15 +234,15 @@ __device__ __forceinline__ R chk_lut(R a, R b, const Lut<R> &L)
 #ifdef POLAR_DOUBLE_CHK  // timing experiment: marginal cost of one more CHK
     {
         const R s2 = b + a * R(1.0000001), d2 = a - b * R(1.0000001);
-        const int is2 = L.idx(s2), id2 = L.idx(d2);
-        const R delta2 = L.dlt[is2 * 8 + id2];
+        const int o2 = L.pick(s2, 0) + L.pick(d2, 16);
+        const R delta2 = *reinterpret_cast<const R *>(reinterpret_cast<const unsigned char *>(L.dlt) + o2);
         const R r2 = xor_sign(minabs(s2, d2), a, b) + delta2;
         __asm__ volatile("" ::"v"(r2));
     }
 #endif
     const R s = a + b, d = a - b;
-    const int is = L.idx(s), id = L.idx(d);
-    const R delta = L.dlt[is * 8 + id];
+    const int os = L.pick(s, 0), od = L.pick(d, 16);
+    const R delta = *reinterpret_cast<const R *>(reinterpret_cast<const unsigned char *>(L.dlt) + (os + od));
     return xor_sign(minabs(a, b), a, b) + delta;
 }
 
@@ -620,7 +667,6 @@ struct FastDec {
         uint32_t crcw = 0;
         if (CRC_ON && !frozen) crcw = crct[j];
         uint32_t bit = 0;
-        const R absl = absr(lam);
 #ifdef POLAR_DOUBLE_PHI
         {
             const R t2 = lut.tabv(lam * R(1.0000001));
@@ -628,12 +674,12 @@ struct FastDec {
         }
 #endif
         const R tt = lut.tabv(lam);
-        const R pen = tt + absl;
-        const R ph0 = (lam < R(0)) ? pen : tt;  // PHI(.,0)  (SCL_1024.c:481-502)
+        // PHI(.,0) = T + (lam < 0 ? |lam| : 0)  (SCL_1024.c:481-502); T + 0 is exact
+        const R ph0 = tt + posmax(-lam);
         if (frozen) {
             PM += ph0;  // SCL_1024.c:601-604, :662-665
         } else {
-            const R ph1 = (lam > R(0)) ? pen : tt;  // PHI(.,1)
+            const R ph1 = tt + posmax(lam);  // PHI(.,1) = T + (lam > 0 ? |lam| : 0)
             if (logact < 3) {
                 // phase 1 (SCL_1024.c:586-600): group q is slot q mod 2^logact; the fork sends the replicas
                 // with bit `logact` of q set down the 1-branch
@@ -711,9 +757,8 @@ struct FastDec {
         y = quad_lanes<0xB1>(x);  // quad_perm [1,0,3,2]: lane ^ 1
         f = chk(x, y); g = x + y;
         const R lam = (pos & 1) ? g : f;
-        const R absl = absr(lam);
         const R tt = lut.tabv(lam);
-        R ph = (lam < R(0)) ? tt + absl : tt;  // PHI(lambda_k, 0) in lane k
+        R ph = tt + posmax(-lam);  // PHI(lambda_k, 0) in lane k
         PM += ph;
         ph = shl_lanes<1>(ph); PM += ph;
         ph = shl_lanes<1>(ph); PM += ph;
