@@ -122,6 +122,9 @@ int polar_time_decode_device(polar_ctx *ctx, const void *d_in, int in_is_f32, do
                              uint32_t *d_uhat_bits, int reps, float *ms_per_launch);
 
 /* introspection */
+/* I[0..A): the unfrozen positions in reliability order this ctx uses (the reference's global I[],
+ * CASCL_1024_L8.c:99, :214-217); n must be >= A. */
+int polar_info_order(const polar_ctx *ctx, int *out, int n);
 int polar_ctx_info(const polar_ctx *ctx, int *N, int *K, int *A, int *L, int *algo, int *dtype);
 /* name of the kernel instantiation this ctx launches (for matching rocprofv3 output) */
 const char *polar_kernel_name(const polar_ctx *ctx);

@@ -76,6 +76,7 @@ def load_library():
     L.polar_time_decode_device.argtypes = [vp, vp, C.c_int, C.c_double, C.c_size_t, vp, C.c_int,
                                            C.POINTER(C.c_float)]
     L.polar_ctx_info.argtypes = [vp, ip, ip, ip, ip, ip, ip]
+    L.polar_info_order.argtypes = [vp, ip, C.c_int]
     L.polar_kernel_name.restype = C.c_char_p
     L.polar_kernel_name.argtypes = [vp]
     L.polar_version.restype = C.c_char_p

@@ -485,6 +485,13 @@ int polar_ctx_info(const polar_ctx *c, int *N, int *K, int *A, int *L, int *algo
     return POLAR_OK;
 }
 
+int polar_info_order(const polar_ctx *c, int *out, int n)
+{
+    if (!c || !out || n < c->A) return POLAR_EINVAL;
+    for (int i = 0; i < c->A; ++i) out[i] = c->info_order[i];
+    return POLAR_OK;
+}
+
 const char *polar_kernel_name(const polar_ctx *c) { return c ? c->kernel_name.c_str() : ""; }
 
 int polar_decode_device(polar_ctx *c, const void *d_in, int in_is_f32, double sigma, size_t B, uint32_t *d_bits,

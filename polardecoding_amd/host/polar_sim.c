@@ -1,0 +1,209 @@
+/*
+ * polar_sim.c -- C host harness over libpolar_hip.so: the reference's main() (SCL_1024.c:136-292,
+ * CASCL_1024_L8.c:143-315) with the per-frame decode call replaced by batched GPU decodes.
+ *
+ * The transmit chain is the reference's, kept sequential on the host so that a fixed SEED reproduces the
+ * published run counts: PN source (SCL_1024.c:184-197), CRC multiply by g(D) (CASCL_1024_L8.c:245-266),
+ * u[I[i]] = w[i], x = u F^{(x)n} (:242-250, butterfly form), y = +-1 + n with n from Marsaglia polar on
+ * Ranq1 (:295-326), std = 10^(-dB/20) (:226).  Frames are produced in order, decoded `batch` at a time
+ * through polar_decode_batch_y (the kernel forms 2*y/std/std), and the reference's sequential stop rule
+ * `for (run = 0; errBlock < BLE; run++)` (:228) is applied by cutting the batch at the frame of the BLE-th
+ * block error and rewinding the generator state to just after that frame (RNG and PN phase carry over
+ * SNR points exactly as in the reference, which never resets them).
+ *
+ * Output lines follow the reference's printf formats (CASCL_1024_L8.c:308, SC_128.c:218-221).
+ *
+ *   polar_sim --algo cascl --N 1024 --K 512 --L 8 --crc 24c --seed 1242 --ble 100 --snr 1.0:2.0:0.5
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "polar_hip.h"
+
+typedef struct {
+    uint64_t seed, ranv;
+    int rani;
+    int m; /* PN phase */
+} gen_state;
+
+static int PN[63];
+
+static void pn_init(void) /* SCL_1024.c:184-197 */
+{
+    int U[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 63; i++) {
+        int b = (i == 0) ? 1 : (i < 6) ? 0 : (U[4] ^ U[5]);
+        PN[i] = b;
+        U[5] = U[4]; U[4] = U[3]; U[3] = U[2]; U[2] = U[1]; U[1] = U[0]; U[0] = b;
+    }
+}
+
+static double ranq1(gen_state *g) /* SCL_1024.c:295-309 */
+{
+    if (g->rani == 0) {
+        g->ranv = g->seed ^ 4101842887655102017ULL;
+        g->ranv ^= g->ranv >> 21; g->ranv ^= g->ranv << 35; g->ranv ^= g->ranv >> 4;
+        g->ranv *= 2685821657736338717ULL;
+        g->rani++;
+    }
+    g->ranv ^= g->ranv >> 21; g->ranv ^= g->ranv << 35; g->ranv ^= g->ranv >> 4;
+    return (double)(g->ranv * 2685821657736338717ULL) * 5.42101086242752217E-20;
+}
+
+static void normal_pair(gen_state *g, double sigma, double *n1, double *n2) /* SCL_1024.c:312-326 */
+{
+    double x1, x2, s;
+    do {
+        x1 = 2 * ranq1(g) - 1;
+        x2 = 2 * ranq1(g) - 1;
+        s = x1 * x1 + x2 * x2;
+    } while (s >= 1.0);
+    *n1 = sigma * x1 * sqrt(-2 * log(s) / s);
+    *n2 = sigma * x2 * sqrt(-2 * log(s) / s);
+}
+
+typedef struct {
+    int N, K, r, A, ntaps;
+    int taps[32];
+    int *I; /* info order */
+} code_t;
+
+static void make_frame(gen_state *g, const code_t *c, double sigma, unsigned char *u, double *y)
+{
+    const int N = c->N;
+    static int w[4096 + 64];
+    static unsigned char x[4096];
+    for (int i = 0; i < c->A; i++) w[i] = 0;
+    for (int i = 0; i < c->K; i++)
+        if (PN[(g->m + i) % 63]) {
+            if (c->r == 0) w[i] ^= 1;
+            else for (int t = 0; t < c->ntaps; t++) w[i + c->taps[t]] ^= 1; /* CASCL_1024_L8.c:251-266 */
+        }
+    memset(u, 0, (size_t)N);
+    for (int i = 0; i < c->A; i++) u[c->I[i]] = (unsigned char)w[i];
+    memcpy(x, u, (size_t)N);
+    for (int s = 1; s < N; s <<= 1)
+        for (int j = 0; j < N; j++)
+            if (!(j & s)) x[j] ^= x[j + s];
+    for (int i = 0; i < N; i += 2) { /* SCL_1024.c:253-261 */
+        double n1, n2;
+        normal_pair(g, sigma, &n1, &n2);
+        y[i] = x[i] ? -1 + n1 : 1 + n1;
+        y[i + 1] = x[i + 1] ? -1 + n2 : 1 + n2;
+    }
+    g->m += c->K % 63; /* :273-274 */
+    if (g->m >= 63) g->m -= 63;
+}
+
+static const int CRC24C[] = {0, 1, 2, 4, 8, 12, 13, 15, 17, 20, 21, 23, 24};
+static const int CRC6[] = {0, 5, 6};
+
+static void usage(void)
+{
+    fprintf(stderr, "usage: polar_sim --algo sc|bp|scl|cascl --N n --K k [--L l] [--crc 24c|6] [--seed s] [--ble b]\n"
+                    "                 [--snr lo:hi:step] [--batch b] [--dtype f64|f32] [--bp-iters i] [--q file]\n");
+    exit(2);
+}
+
+int main(int argc, char **argv)
+{
+    int N = 1024, K = 512, L = 8, algo = POLAR_ALGO_CASCL, ble = 100, batch = 4096, dtype = POLAR_F64, bp_iters = 100;
+    uint64_t seed = 1024;
+    double lo = 1.0, hi = 3.0, step = 0.5;
+    const char *crc = NULL, *qfile = NULL;
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        const char *v = (i + 1 < argc) ? argv[i + 1] : NULL;
+        if (!strcmp(a, "--algo") && v) {
+            algo = !strcmp(v, "sc") ? POLAR_ALGO_SC : !strcmp(v, "bp") ? POLAR_ALGO_BP
+                 : !strcmp(v, "scl") ? POLAR_ALGO_SCL : !strcmp(v, "cascl") ? POLAR_ALGO_CASCL : -1;
+            if (algo < 0) usage();
+            i++;
+        } else if (!strcmp(a, "--N") && v) { N = atoi(v); i++; }
+        else if (!strcmp(a, "--K") && v) { K = atoi(v); i++; }
+        else if (!strcmp(a, "--L") && v) { L = atoi(v); i++; }
+        else if (!strcmp(a, "--crc") && v) { crc = v; i++; }
+        else if (!strcmp(a, "--seed") && v) { seed = strtoull(v, NULL, 10); i++; }
+        else if (!strcmp(a, "--ble") && v) { ble = atoi(v); i++; }
+        else if (!strcmp(a, "--batch") && v) { batch = atoi(v); i++; }
+        else if (!strcmp(a, "--bp-iters") && v) { bp_iters = atoi(v); i++; }
+        else if (!strcmp(a, "--q") && v) { qfile = v; i++; }
+        else if (!strcmp(a, "--dtype") && v) { dtype = !strcmp(v, "f32") ? POLAR_F32 : POLAR_F64; i++; }
+        else if (!strcmp(a, "--snr") && v) {
+            if (sscanf(v, "%lf:%lf:%lf", &lo, &hi, &step) != 3) usage();
+            i++;
+        } else usage();
+    }
+    if (N > 4096 || N < 32) usage();
+    code_t c;
+    memset(&c, 0, sizeof c);
+    c.N = N; c.K = K;
+    if (algo == POLAR_ALGO_CASCL) {
+        if (!crc) crc = (N == 128) ? "6" : "24c";
+        const int *t = !strcmp(crc, "6") ? CRC6 : CRC24C;
+        c.ntaps = !strcmp(crc, "6") ? 3 : 13;
+        memcpy(c.taps, t, sizeof(int) * (size_t)c.ntaps);
+        c.r = c.taps[c.ntaps - 1];
+    }
+    c.A = K + c.r;
+    (void)qfile;
+
+    polar_cfg cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.N = N; cfg.K = K; cfg.crc_r = c.r; cfg.crc_taps = c.r ? c.taps : NULL; cfg.n_taps = c.ntaps;
+    cfg.L = L; cfg.algo = algo; cfg.bp_iters = bp_iters; cfg.info_order = NULL; cfg.dtype = dtype; cfg.device = 0;
+    polar_ctx *ctx = NULL;
+    int rc = polar_create(&cfg, &ctx);
+    if (rc) { fprintf(stderr, "polar_create: %s\n", polar_strerror(rc)); return 1; }
+    /* the library built the frozen set from the 5G sequence like the reference (I[i] = Q[N-(K+r)+i]);
+       the encoder needs the same I[] */
+    c.I = (int *)malloc(sizeof(int) * (size_t)c.A);
+    if (polar_info_order(ctx, c.I, c.A) != 0) { fprintf(stderr, "polar_info_order failed\n"); return 1; }
+
+    pn_init();
+    gen_state g = {seed, 0, 0, 0};
+    double *y = (double *)malloc(sizeof(double) * (size_t)batch * N);
+    unsigned char *u = (unsigned char *)malloc((size_t)batch * N);
+    int *uh = (int *)malloc(sizeof(int) * (size_t)batch * N);
+    gen_state *after = (gen_state *)malloc(sizeof(gen_state) * (size_t)batch);
+    printf("SEED = %llu\n", (unsigned long long)seed);
+    for (double db = lo; db <= hi + 1e-12; db += step) {
+        const double sigma = pow(10, db / ((double)-20)); /* :226 */
+        long run = 0, errbit = 0;
+        int errblock = 0;
+        while (errblock < ble) {
+            for (int f = 0; f < batch; f++) {
+                make_frame(&g, &c, sigma, u + (size_t)f * N, y + (size_t)f * N);
+                after[f] = g;
+            }
+            rc = polar_decode_batch_y(ctx, y, sigma, (size_t)batch, uh, NULL, NULL);
+            if (rc) { fprintf(stderr, "decode: %s (%s)\n", polar_strerror(rc), polar_last_error(ctx)); return 1; }
+            int f;
+            for (f = 0; f < batch && errblock < ble; f++) { /* :296-305 */
+                int e = 0;
+                for (int i = 0; i < c.A; i++) {
+                    const int j = c.I[i];
+                    e += (u[(size_t)f * N + j] != (unsigned char)uh[(size_t)f * N + j]);
+                }
+                errbit += e;
+                errblock += (e != 0);
+                run++;
+            }
+            if (errblock >= ble) g = after[f - 1]; /* rewind to just after the frame that hit the stop rule */
+        }
+        if (algo == POLAR_ALGO_SC || algo == POLAR_ALGO_BP) {
+            printf("bSNR = %.2lf\terror block = %d\trun = %ld\tBLER = %lf\n", db, errblock, run, (double)errblock / run);
+            printf("Error bit = %ld\tBER = %lf\n", errbit, (double)errbit / K / run);
+        } else {
+            printf("L = %d\tbSNR = %.2lf\terror block = %d\trun = %ld\tBLER = %lfe-4\n", L, db, errblock, run,
+                   (double)errblock / (run / 10000.0));
+        }
+        fflush(stdout);
+    }
+    polar_destroy(ctx);
+    free(y); free(u); free(uh); free(after); free(c.I);
+    return 0;
+}

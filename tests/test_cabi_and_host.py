@@ -1,0 +1,136 @@
+"""CPU: the C-ABI library loads and exports every symbol include/polar_hip.h declares (no compute calls
+without a GPU), argument validation, host-side helpers, and the N > 1 path under gloo with world_size 2."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+def _lib():
+    import polardecoding_amd as pa
+    if not os.path.exists(pa.lib_path()):
+        import __graft_entry__ as g
+        g.build()
+    return pa.load_library()
+
+
+def test_every_declared_symbol_is_exported():
+    lib = _lib()
+    hdr = open(os.path.join(REPO, "include", "polar_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(polar_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in polar_hip.h but not exported"
+
+
+def test_version_and_strerror():
+    lib = _lib()
+    assert b"gfx950" in lib.polar_version()
+    assert lib.polar_strerror(0) == b"ok"
+    assert b"invalid" in lib.polar_strerror(-1)
+
+
+def test_create_rejects_bad_configs_before_touching_a_device():
+    import polardecoding_amd as pa
+    _lib()
+    with pytest.raises(pa.PolarError):
+        pa.Decoder(1000, 512, pa.ALGO_SCL, L=8)        # N not a power of two
+    with pytest.raises(pa.PolarError):
+        pa.Decoder(1024, 512, pa.ALGO_SCL, L=3)        # L not a power of two
+    with pytest.raises(pa.PolarError):
+        pa.Decoder(1024, 2000, pa.ALGO_SCL, L=8)       # K > N
+    with pytest.raises(pa.PolarError):
+        pa.Decoder(1024, 512, pa.ALGO_CASCL, L=8)      # CA-SCL without CRC taps
+    with pytest.raises(pa.PolarError):
+        pa.Decoder(1024, 512, pa.ALGO_CASCL, L=8, crc_taps=(1, 5, 6))  # g(D) without D^0
+
+
+def test_no_cpu_fallback_in_product_package():
+    """The product path must not import or call the oracle."""
+    pkg = os.path.join(REPO, "polardecoding_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".c", ".cpp")):
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert "oracle_py" not in text and "polar_oracle" not in text, f
+
+
+def test_q_sequence_matches_oracle_table(oracle):
+    import polardecoding_amd as pa
+    assert pa.q_sequence(1024) == oracle.q_for(1024)
+    assert pa.q_sequence(128) == oracle.q_for(128)
+
+
+def test_frame_shard_partition():
+    from polardecoding_amd.montecarlo import frame_shard
+    for total in (0, 1, 7, 1 << 20, 12345):
+        for world in (1, 2, 3, 8):
+            spans = [frame_shard(total, r, world) for r in range(world)]
+            assert sum(c for _, c in spans) == total
+            pos = 0
+            for s, c in spans:
+                assert s == pos
+                pos += c
+
+
+def test_sequential_stop_cut():
+    from polardecoding_amd.montecarlo import sequential_stop_cut
+    fe = [0, 3, 0, 0, 1, 0, 2, 0]
+    assert sequential_stop_cut(fe, 2) == (5, 2, 4)
+    assert sequential_stop_cut(fe, 3) == (7, 3, 6)
+    assert sequential_stop_cut(fe, 4) is None
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, {repo!r})
+import numpy as np, torch, torch.distributed as dist
+from oracle import oracle_py as O            # checker standing in for the GPU decoder in this CPU test
+from polardecoding_amd.montecarlo import fer_point
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+code = O.Code(128, 64, O.CRC6_TAPS)
+sig = O.sigma_from_db(1.5)
+us, ys = O.Sim(77).frames(code, sig, 96)     # every rank draws the same frame list and decodes only its shard
+def dec(start, count):
+    blk = bits = 0
+    for i in range(start, start + count):
+        uh, _, _ = O.decode(code, O.llr_from_y(ys[i], sig), "CASCL", L=8)
+        e = O.count_bit_errors(code, us[i], uh)
+        blk += e > 0; bits += e
+    return blk, bits
+res = fer_point(dec, 96, rank, world, dist)
+if rank == 0:
+    print("RESULT", res[0], res[1], res[2])
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_matches_single_process(oracle, tmp_path):
+    """world_size-2 gloo run of the sharded FER point == the single-process count over the same frames."""
+    code = oracle.Code(128, 64, oracle.CRC6_TAPS)
+    sig = oracle.sigma_from_db(1.5)
+    us, ys = oracle.Sim(77).frames(code, sig, 96)
+    blk = bits = 0
+    for i in range(96):
+        uh, _, _ = oracle.decode(code, oracle.llr_from_y(ys[i], sig), "CASCL", L=8)
+        e = oracle.count_bit_errors(code, us[i], uh)
+        blk += e > 0
+        bits += e
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(repo=REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT")][0].split()
+    assert [int(x) for x in line[1:]] == [blk, bits, 96]

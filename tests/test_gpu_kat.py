@@ -1,0 +1,52 @@
+"""GPU: the reference's published fixed-seed run counts reproduced END TO END by the C host harness
+(polardecoding_amd/host/polar_sim.c -> libpolar_hip.so -> HIP kernels): sequential transmit chain on the
+host, batched decode on the GPU, reference stop rule.  Any single wrong decision changes a count."""
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, REPO
+
+pytestmark = pytest.mark.gpu
+SIM = os.path.join(REPO, "polardecoding_amd", "lib", "polar_sim")
+
+with open(os.path.join(GOLDEN, "published_runs.json")) as f:
+    PUB = json.load(f)
+
+
+def published(key, seed, L, n):
+    for b in PUB[key]:
+        if b["seed"] == seed and b["L"] == L:
+            return [r[2] for r in b["rows"][:n]], b["rows"][0][1]
+    raise KeyError
+
+
+def run_sim(args):
+    out = subprocess.run([SIM] + args, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [int(x) for x in re.findall(r"run = (\d+)", out.stdout)], out.stdout
+
+
+CASES = [
+    # (log, seed, L, points, args)
+    ("myResult_128/SC128out.txt", 1024, 1, 5, ["--algo", "sc", "--N", "128", "--K", "64", "--snr", "1.0:3.0:0.5"]),
+    ("myResult_1024/SC1024out.dat", 1024, 1, 3, ["--algo", "sc", "--N", "1024", "--K", "512", "--snr", "1.0:2.0:0.5"]),
+    ("myResult_128/SCL128out_errblock50.dat", 1024, 8, 4, ["--algo", "scl", "--N", "128", "--K", "64", "--L", "8", "--snr", "1.0:2.5:0.5"]),
+    ("myResult_128/SCL128out_errblock50.dat", 1024, 4, 3, ["--algo", "scl", "--N", "128", "--K", "64", "--L", "4", "--snr", "1.0:2.0:0.5"]),
+    ("myResult_128/CASCL_128_L8.txt", 8392, 8, 4, ["--algo", "cascl", "--N", "128", "--K", "64", "--L", "8", "--crc", "6", "--snr", "1.0:2.5:0.5"]),
+    ("myResult_1024/SCL1024out.dat", 1024, 8, 3, ["--algo", "scl", "--N", "1024", "--K", "512", "--L", "8", "--snr", "1.0:2.0:0.5"]),
+    ("myResult_1024/SCL1024out.dat", 1024, 2, 3, ["--algo", "scl", "--N", "1024", "--K", "512", "--L", "2", "--snr", "1.0:2.0:0.5"]),
+    ("myResult_1024/CASCL_L8.dat", 1242, 8, 3, ["--algo", "cascl", "--N", "1024", "--K", "512", "--L", "8", "--crc", "24c", "--snr", "1.0:2.0:0.5"]),
+    ("myResult_1024/CASCL_L8.dat", 5139, 8, 2, ["--algo", "cascl", "--N", "1024", "--K", "512", "--L", "8", "--crc", "24c", "--snr", "1.0:1.5:0.5"]),
+]
+
+
+@pytest.mark.parametrize("key,seed,L,n,args", CASES, ids=[f"{c[0].split('/')[1]}-s{c[1]}-L{c[2]}" for c in CASES])
+def test_published_run_counts(key, seed, L, n, args):
+    assert os.path.exists(SIM), "polar_sim not built (run __graft_entry__.build())"
+    exp, ble = published(key, seed, L, n)
+    got, text = run_sim(args + ["--seed", str(seed), "--ble", str(ble), "--batch", "512"])
+    assert got == exp, text

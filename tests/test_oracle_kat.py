@@ -1,0 +1,55 @@
+"""CPU: known-answer run counts published by the reference (myResult_*.zip logs -> tests/golden/
+published_runs.json) reproduced by the oracle's decoder + restated harness: pins the WHOLE chain
+PN -> CRC -> encode -> AWGN (Ranq1 + Marsaglia) -> decode -> count with the sequential stop rule."""
+import json
+import os
+
+import pytest
+
+from conftest import GOLDEN
+
+with open(os.path.join(GOLDEN, "published_runs.json")) as f:
+    PUB = json.load(f)
+
+
+def rows(key, seed, L):
+    for b in PUB[key]:
+        if b["seed"] == seed and b["L"] == L:
+            return b["rows"]
+    raise KeyError((key, seed, L))
+
+
+def check(oracle, code, algo, key, seed, L, npoints):
+    r = rows(key, seed, L)[:npoints]
+    snr = [x[0] for x in r]
+    ble = r[0][1]
+    run, _ = oracle.run_sweep(code, algo, snr, ble, seed, L=L)
+    assert run == [x[2] for x in r], f"{key} seed {seed} L {L}"
+
+
+def test_sc128_all_points(oracle):
+    check(oracle, oracle.Code(128, 64), "SC", "myResult_128/SC128out.txt", 1024, 1, 7)
+
+
+def test_sc1024(oracle):
+    check(oracle, oracle.Code(1024, 512), "SC", "myResult_1024/SC1024out.dat", 1024, 1, 4)
+
+
+@pytest.mark.parametrize("L", [2, 4, 8, 16, 32])
+def test_scl128_list_sizes(oracle, L):
+    check(oracle, oracle.Code(128, 64), "SCL", "myResult_128/SCL128out_errblock50.dat", 1024, L, 5 if L <= 8 else 4)
+
+
+@pytest.mark.parametrize("seed", [8392, 8642])
+def test_cascl128_crc6(oracle, seed):
+    check(oracle, oracle.Code(128, 64, oracle.CRC6_TAPS), "CASCL", "myResult_128/CASCL_128_L8.txt", seed, 8, 4)
+
+
+@pytest.mark.parametrize("L,npts", [(2, 3), (8, 2), (32, 1)])
+def test_scl1024(oracle, L, npts):
+    check(oracle, oracle.Code(1024, 512), "SCL", "myResult_1024/SCL1024out.dat", 1024, L, npts)
+
+
+@pytest.mark.parametrize("seed", [1242, 5139])
+def test_cascl1024_crc24(oracle, seed):
+    check(oracle, oracle.Code(1024, 512, oracle.CRC24C_TAPS), "CASCL", "myResult_1024/CASCL_L8.dat", seed, 8, 2)
