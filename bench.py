@@ -175,6 +175,15 @@ def main():
     alg_bytes = B * (N * in_bytes + N // 8)  # LLRs in, packed bits out
     achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9
 
+    traffic = None
+    try:  # measured separately with rocprofv3 --pmc (profiles/README.md); only valid for the profiled workload
+        with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
+            tj = json.load(f).get(args.dtype)
+        if tj and tj["frames_per_launch"] == B:
+            traffic = (tj["fetch_kib"] + tj["write_kib"]) * 1024.0
+    except Exception:
+        traffic = None
+
     if rank == 0:
         total_frames = world * B * args.steps
         value = total_frames / elapsed
@@ -197,7 +206,7 @@ def main():
             "fer": {"block_errors": blk, "bit_errors": bits, "frames": world * B,
                     "fer": blk / float(world * B)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": dec.kernel_name, "kernel_ms": ms_kernel,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "path is VALU/LDS-bound, not HBM-bound (SURVEY.md 0.5); see DESIGN.md"},

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Summarise a tools/prof_pmc.sh output directory into a small text file for profiles/.
+usage: summarize_prof.py gpurun_out/profN frames_per_launch > profiles/rNN_xxx.txt"""
+import collections, csv, glob, sys
+d, frames = sys.argv[1], int(sys.argv[2])
+print(f"# rocprofv3 summary of {d} (frames per launch = {frames})")
+for f in glob.glob(f"{d}/stats/*/*_kernel_stats.csv"):
+    rows = list(csv.DictReader(open(f)))
+    print("## kernel-trace --stats (top kernels)")
+    print("Name,Calls,TotalDurationNs,AverageNs,Percentage")
+    for r in rows[:4]:
+        print(",".join([r["Name"][:70], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]]))
+print("## PMC (sum over the chip, per dispatch of the decode kernel, and per frame)")
+for sub in sorted(glob.glob(f"{d}/pmc*")):
+    for f in glob.glob(f"{sub}/*/*_counter_collection.csv"):
+        rows = list(csv.DictReader(open(f)))
+        agg = collections.defaultdict(float)
+        disp = set()
+        for r in rows:
+            if "k_scl" in r["Kernel_Name"] or "k_bp" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]] += float(r["Counter_Value"])
+                disp.add(r["Dispatch_Id"])
+        for c, v in sorted(agg.items()):
+            per = v / max(1, len(disp))
+            print(f"{c:24s} {per:16.6g} per dispatch {per / frames:14.3f} per frame   ({len(disp)} dispatches)")
