@@ -37,6 +37,35 @@ __device__ __forceinline__ int dpp_i(int v)
 {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
+template <int K>  // lane i <- lane i+K within its row of 16 (row_shl), every lane valid
+__device__ __forceinline__ double shl_true(double x)
+{
+    long long b = __double_as_longlong(x);
+    int lo = dpp_i<0x100 + K>((int)b), hi = dpp_i<0x100 + K>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int K>
+__device__ __forceinline__ float shl_true(float x)
+{
+    return __int_as_float(dpp_i<0x100 + K>(__float_as_int(x)));
+}
+#ifdef POLAR_SWIZZLE_PARTNER
+// lane i <- lane i^K through the LDS crossbar (no VALU slot); equals lane i+K for the low lanes that are used
+template <int K>
+__device__ __forceinline__ double shl_lanes(double x)
+{
+    long long b = __double_as_longlong(x);
+    int lo = __builtin_amdgcn_ds_swizzle((int)b, (K << 10) | 0x1F), hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), (K << 10) | 0x1F);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int K>
+__device__ __forceinline__ float shl_lanes(float x)
+{
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), (K << 10) | 0x1F));
+}
+#define POLAR_SHL_DEFINED
+#endif
+#ifndef POLAR_SHL_DEFINED
 template <int K>  // lane i <- lane i+K within its row of 16 (row_shl)
 __device__ __forceinline__ double shl_lanes(double x)
 {
@@ -49,6 +78,7 @@ __device__ __forceinline__ float shl_lanes(float x)
 {
     return __int_as_float(dpp_i<0x100 + K>(__float_as_int(x)));
 }
+#endif
 template <int K>  // lane i <- lane i-K within its row (row_shr)
 __device__ __forceinline__ double shr_lanes(double x)
 {
@@ -101,6 +131,20 @@ __device__ __forceinline__ float posmax(float x)
     return m;
 }
 
+// max(-x, 0)
+__device__ __forceinline__ double negmax(double x)
+{
+    double m;
+    __asm__("v_max_f64 %0, -%1, 0" : "=v"(m) : "v"(x));
+    return m;
+}
+__device__ __forceinline__ float negmax(float x)
+{
+    float m;
+    __asm__("v_max_f32_e64 %0, -%1, 0" : "=v"(m) : "v"(x));
+    return m;
+}
+
 __device__ __forceinline__ void lds_fence() { __asm__ volatile("" ::: "memory"); }
 
 // ---- table-driven staircase -----------------------------------------------------------------------
@@ -124,7 +168,7 @@ struct Cell<float> {
 
 template <typename R>
 struct Lut {
-    struct __attribute__((aligned(16))) Q { R thr; int lo, hi; };       // 16 bytes (f32: 12 + tail padding)
+    struct __attribute__((aligned(16))) Q { R thr; int pad_[(8 - sizeof(R)) / 4 + 0]; int lo, hi; };  // {thr @0, lo @8, hi @12}
     struct __attribute__((aligned(16))) TP { R lo, hi; };
     static constexpr int NCELL = 50, STRIDE = 48;
     static constexpr size_t cell_bytes = (size_t)NCELL * STRIDE;
@@ -145,18 +189,14 @@ struct Lut {
         __asm__ volatile("" : "+s"(base));  // opaque: keeps the bias inside the multiply-add, offsets in the ds_read
         dlt = reinterpret_cast<const R *>(tab + cell_bytes);
     }
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ double thr_of(u4 q, double) { return __hiloint2double((int)q.y, (int)q.x); }
-    static __device__ __forceinline__ float thr_of(u4 q, float) { return __int_as_float((int)q.x); }
-    static __device__ __forceinline__ int lo_of(u4 q, double) { return (int)q.z; }
-    static __device__ __forceinline__ int hi_of(u4 q, double) { return (int)q.w; }
-    static __device__ __forceinline__ int lo_of(u4 q, float) { return (int)q.y; }
-    static __device__ __forceinline__ int hi_of(u4 q, float) { return (int)q.z; }
-    // offset selected by the exact compare |x| >= thr of the 16-byte sub-entry at byte offset `sub`
+    typedef int i2 __attribute__((ext_vector_type(2)));
+    // offset selected by the exact compare |x| >= thr of the 16-byte sub-entry {thr @0, (lo, hi) @8} at `sub`
     __device__ __forceinline__ int pick(R x, unsigned sub) const
     {
-        const u4 q = *reinterpret_cast<const u4 *>(lds0 + entry(x) + sub);
-        return (absr(x) >= thr_of(q, R(0))) ? hi_of(q, R(0)) : lo_of(q, R(0));
+        const unsigned e = entry(x) + sub;
+        const R thr = *reinterpret_cast<const R *>(lds0 + e);
+        const i2 lh = *reinterpret_cast<const i2 *>(lds0 + e + 8);
+        return (absr(x) >= thr) ? lh.y : lh.x;
     }
     // executed by a whole workgroup before its first barrier
     static __device__ void build(unsigned char *tab, int tid, int nthreads)
@@ -675,7 +715,7 @@ struct FastDec {
 #endif
         const R tt = lut.tabv(lam);
         // PHI(.,0) = T + (lam < 0 ? |lam| : 0)  (SCL_1024.c:481-502); T + 0 is exact
-        const R ph0 = tt + posmax(-lam);
+        const R ph0 = tt + negmax(lam);
         if (frozen) {
             PM += ph0;  // SCL_1024.c:601-604, :662-665
         } else {
@@ -758,20 +798,20 @@ struct FastDec {
         f = chk(x, y); g = x + y;
         const R lam = (pos & 1) ? g : f;
         const R tt = lut.tabv(lam);
-        R ph = tt + posmax(-lam);  // PHI(lambda_k, 0) in lane k
+        R ph = tt + negmax(lam);  // PHI(lambda_k, 0) in lane k
         PM += ph;
-        ph = shl_lanes<1>(ph); PM += ph;
-        ph = shl_lanes<1>(ph); PM += ph;
-        ph = shl_lanes<1>(ph); PM += ph;
-        ph = shl_lanes<1>(ph); PM += ph;
-        ph = shl_lanes<1>(ph); PM += ph;
-        ph = shl_lanes<1>(ph); PM += ph;
+        ph = shl_true<1>(ph); PM += ph;
+        ph = shl_true<1>(ph); PM += ph;
+        ph = shl_true<1>(ph); PM += ph;
+        ph = shl_true<1>(ph); PM += ph;
+        ph = shl_true<1>(ph); PM += ph;
+        ph = shl_true<1>(ph); PM += ph;
         bl0 &= ~0xFEu;  // partial sums of levels 0..2 inside this octet: all zero
         if (last_frozen) {
-            ph = shl_lanes<1>(ph); PM += ph;
+            ph = shl_true<1>(ph); PM += ph;
             set_bit_tail(8 * o + 7, 0u);
         } else {
-            decide<7>(o, false, shl_lanes<7>(lam));
+            decide<7>(o, false, shl_true<7>(lam));
         }
     }
 
