@@ -125,6 +125,13 @@ class Decoder:
         self.A, self.L = A.value, Lr.value
         self.NW = N // 32
 
+    @property
+    def info_order(self):
+        """I[0..A): unfrozen positions in reliability order (the reference's global I[])."""
+        out = np.zeros(self.A, dtype=np.int32)
+        self._check(self._lib.polar_info_order(self._h, _ptr(out, C.c_int), self.A), "polar_info_order")
+        return out
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             self._lib.polar_destroy(self._h)

@@ -49,6 +49,7 @@ struct polar_ctx {
     std::string last_error;
     std::string kernel_name;
     bool force_generic = false;
+    bool force_spill = false;   // POLAR_FORCE_SPILL=1: exercise the global-scratch variant on shapes that would fit LDS
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -124,22 +125,39 @@ std::vector<uint32_t> make_crc_table(int N, int r, const std::vector<int> &taps,
     return tab;
 }
 
-template <typename R, typename IN, int LOGL>
-int launch_scl(polar_ctx *c, const polar::SclParams &P)
+template <typename R, typename IN, int LOGL, bool GA>
+int launch_scl_v(polar_ctx *c, const polar::SclParams &P)
 {
-    auto kern = polar::k_scl_generic<R, IN, LOGL>;
-    const size_t lds = polar::scl_generic_lds_bytes<R, LOGL>(P.N);
+    auto kern = polar::k_scl_generic<R, IN, LOGL, GA>;
+    const size_t lds = polar::scl_generic_lds_bytes<R, LOGL>(P.N, GA);
     if (lds > 160 * 1024) return POLAR_ENOKERNEL;
     HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
     int occ = 0;
     HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, lds));
     if (occ < 1) occ = 1;
+    if (GA && occ > 8) occ = 8;
     int grid = std::min<long long>((long long)P.B, (long long)occ * c->num_cu);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, c->stream, P);
+    polar::SclParams Q = P;
+    if (GA) {
+        const size_t bytes = sizeof(R) * (size_t)((1 << LOGL) + 1) * P.N * (size_t)grid;
+        int rc = ensure(c, c->scratch, bytes);
+        if (rc) return rc;
+        Q.scratch = c->scratch.p;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
     return POLAR_OK;
+}
+
+// LDS-resident levels when they fit (160 KB per CU), else the global-scratch variant
+template <typename R, typename IN, int LOGL>
+int launch_scl(polar_ctx *c, const polar::SclParams &P)
+{
+    if (polar::scl_generic_lds_bytes<R, LOGL>(P.N, false) <= 160 * 1024 && !c->force_spill)
+        return launch_scl_v<R, IN, LOGL, false>(c, P);
+    return launch_scl_v<R, IN, LOGL, true>(c, P);
 }
 
 template <typename R, typename IN>
@@ -427,6 +445,7 @@ int polar_create(const polar_cfg *cfg, polar_ctx **out)
         snprintf(nm, sizeof nm, "k_scl_generic<%s,L=%d>", cfg->dtype == POLAR_F32 ? "float" : "double", L);
     c->kernel_name = nm;
     if (const char *e = getenv("POLAR_FORCE_GENERIC")) c->force_generic = (e[0] == '1');
+    if (const char *e = getenv("POLAR_FORCE_SPILL")) c->force_spill = (e[0] == '1');
     if (fast_ok(c, cfg->dtype == POLAR_F32)) {
         snprintf(nm, sizeof nm, "k_scl_fast<%s,N=%d,L=8>", cfg->dtype == POLAR_F32 ? "float" : "double", N);
         c->kernel_name = nm;

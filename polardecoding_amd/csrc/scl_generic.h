@@ -52,7 +52,14 @@ __device__ __forceinline__ uint64_t ptr_set(uint64_t tbl, int t, int v)
     return (tbl & ~m) | ((uint64_t)v << (t * LOGL));
 }
 
-template <typename R, typename IN, int LOGL>
+// scratch loads that must not be served from a stale per-CU L1 line (relaxed agent-scope atomic = sc1 load)
+__device__ __forceinline__ double ld_bypass(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_bypass(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// GA = false: every LLR level of every path in LDS.  GA = true ("LLRs spill HBM", BASELINE config 5): the
+// level arrays alpha[L][N] live in a per-workgroup slice of a global scratch buffer and the channel LLRs are
+// read from the input; only the bit-packed partial sums stay in LDS.
+template <typename R, typename IN, int LOGL, bool GA>
 __global__ __launch_bounds__(64) void k_scl_generic(SclParams P)
 {
     constexpr int L = 1 << LOGL;
@@ -62,11 +69,23 @@ __global__ __launch_bounds__(64) void k_scl_generic(SclParams P)
     const int p = lane / S, pos = lane % S;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    R *ch = reinterpret_cast<R *>(smem);
-    R *alpha = ch + N;
-    uint32_t *blw = reinterpret_cast<uint32_t *>(alpha + (size_t)L * N);
+    R *ch, *alpha;
+    uint32_t *blw;
+    if constexpr (GA) {
+        ch = reinterpret_cast<R *>(P.scratch) + (size_t)blockIdx.x * (size_t)(L + 1) * N;
+        alpha = ch + N;
+        blw = reinterpret_cast<uint32_t *>(smem);
+    } else {
+        ch = reinterpret_cast<R *>(smem);
+        alpha = ch + N;
+        blw = reinterpret_cast<uint32_t *>(alpha + (size_t)L * N);
+    }
     uint32_t *curw = blw + (size_t)L * NW;
     R *cand = reinterpret_cast<R *>(curw + (size_t)L * NW);
+    auto ld = [](const R *q) -> R {
+        if constexpr (GA) return ld_bypass(q);
+        else return *q;
+    };
 
     for (int frame = blockIdx.x; frame < P.B; frame += gridDim.x) {
         // ---- channel LLRs (SCL_1024.c:574-578) ----
@@ -98,7 +117,7 @@ __global__ __launch_bounds__(64) void k_scl_generic(SclParams P)
                     for (int e = pos; e < h; e += S) {
                         const int bi = h + e;
                         const uint32_t wv = (bi < 32) ? bl0 : blw[p * NW + (bi >> 5)];
-                        out[e] = gfun<R>(src[e], src[e + h], (wv >> (bi & 31)) & 1);
+                        out[e] = gfun<R>(ld(src + e), ld(src + e + h), (wv >> (bi & 31)) & 1);
                     }
                     ptrA = ptr_set<LOGL>(ptrA, d, p);
                 }
@@ -112,12 +131,12 @@ __global__ __launch_bounds__(64) void k_scl_generic(SclParams P)
                 if (p < act) {
                     const R *src = (t + 1 == n) ? ch : alpha + (size_t)ptr_get<LOGL>(ptrA, t + 1) * N + (2 << t);
                     R *out = alpha + (size_t)p * N + h;
-                    for (int e = pos; e < h; e += S) out[e] = chk<R>(src[e], src[e + h]);
+                    for (int e = pos; e < h; e += S) out[e] = chk<R>(ld(src + e), ld(src + e + h));
                     ptrA = ptr_set<LOGL>(ptrA, t, p);
                 }
                 __syncthreads();
             }
-            const R lam = (p < act) ? alpha[(size_t)p * N + 1] : R(0);
+            const R lam = (p < act) ? ld(alpha + (size_t)p * N + 1) : R(0);
 
             // ================= decision =================
             const bool frozen = (P.frozen[j >> 5] >> (j & 31)) & 1;
@@ -310,9 +329,9 @@ __global__ __launch_bounds__(64) void k_scl_generic(SclParams P)
 }
 
 template <typename R, int LOGL>
-constexpr size_t scl_generic_lds_bytes(int N)
+constexpr size_t scl_generic_lds_bytes(int N, bool ga)
 {
-    return sizeof(R) * (size_t)N * (1 + (1 << LOGL)) + 2 * sizeof(uint32_t) * (size_t)(N / 32) * (1 << LOGL) +
+    return (ga ? 0 : sizeof(R) * (size_t)N * (1 + (1 << LOGL))) + 2 * sizeof(uint32_t) * (size_t)(N / 32) * (1 << LOGL) +
            sizeof(R) * 2 * (1 << LOGL);
 }
 

@@ -79,6 +79,48 @@ def test_scl_list_sizes_vs_oracle(N, K, L, oracle):
     assert np.array_equal(pm, ref_pm)
 
 
+def _oracle_code_like(oracle, dec, N, K, taps):
+    """oracle Code with exactly the decoder's information order (needed above N = 1024, where the reference
+    has no reliability table and the library builds the beta-expansion order)."""
+    io = dec.info_order
+    rest = [j for j in range(N) if j not in set(io.tolist())]
+    return oracle.Code(N, K, taps, Q=rest + io.tolist())
+
+
+@pytest.mark.parametrize("N,K,L,crc", [(4096, 2048, 32, True), (4096, 2048, 8, False), (2048, 1024, 16, True)])
+def test_config5_spilled_levels_vs_oracle(N, K, L, crc, oracle):
+    """BASELINE config 5 (N=4096 K=2048 CA-SCL L=32; no counterpart in the reference: parity unpinned,
+    oracle <-> GPU self-consistency only).  LLR levels live in global scratch ("LLRs spill HBM")."""
+    import polardecoding_amd as pa
+    taps = pa.CRC24C_TAPS if crc else None
+    dec = pa.CASCL(N, K, L=L, crc_taps=taps) if crc else pa.SCLdecode(N, K, L=L)
+    code = _oracle_code_like(oracle, dec, N, K, taps)
+    sim = oracle.Sim(31 + L)
+    sig = oracle.sigma_from_db(1.5)
+    B = 6
+    us, ys = sim.frames(code, sig, B)
+    llr = np.stack([oracle.llr_from_y(y, sig) for y in ys])
+    ref_uh, ref_pm, _ = oracle.decode(code, llr, "CASCL" if crc else "SCL", L=L)
+    uh, pm, fl = dec.decode_batch(llr)
+    assert np.array_equal(uh, ref_uh)
+    assert np.array_equal(pm, ref_pm)
+
+
+def test_forced_spill_matches_golden(monkeypatch):
+    """The global-scratch variant on a shape that also fits LDS: same bits as the reference."""
+    import polardecoding_amd as pa
+    monkeypatch.setenv("POLAR_FORCE_SPILL", "1")
+    monkeypatch.setenv("POLAR_FORCE_GENERIC", "1")
+    g = load_golden("CASCL_1024_L8")
+    dec = pa.CASCL(1024, 512, L=8)
+    assert "generic" in dec.kernel_name
+    for s in np.unique(g["sigma"]):
+        sel = g["sigma"] == s
+        uh, pm, fl = dec.decode_batch_y(g["y"][sel], float(s))
+        assert np.array_equal(uh, g["u_hat"][sel].astype(np.int32))
+        assert np.array_equal(pm, g["pm"][sel])
+
+
 @pytest.mark.parametrize("name", ["SC_1024", "SCL_1024", "CASCL_1024_L8", "CASCL_128", "BP_128"])
 def test_f32_matches_f32_oracle(name, oracle):
     """The f32 kernels keep the operation order: bit-identical to the oracle's f32 instantiation."""
