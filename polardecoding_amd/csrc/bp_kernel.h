@@ -9,6 +9,7 @@
 // Stage order, operand order inside CHK and inside the sums are the reference's.
 #pragma once
 #include "polar_math.h"
+#include "polar_lut.h"
 
 namespace polar {
 
@@ -30,6 +31,12 @@ __global__ __launch_bounds__(512) void k_bp(BpParams P)
     R *lm = ch + N;                       // rows 1..n-1 of l
     R *rm = lm + (size_t)(n - 1) * N;     // rows 1..n-1 of r
     uint32_t *obits = reinterpret_cast<uint32_t *>(rm + (size_t)(n - 1) * N);  // [NW]
+    unsigned char *lut_mem = reinterpret_cast<unsigned char *>(obits + NW);
+    lut_mem += (16 - (reinterpret_cast<uintptr_t>(lut_mem) & 15)) & 15;
+    Lut<R>::build(lut_mem, tid, nt);
+    Lut<R> lut;
+    lut.bind(lut_mem);
+    __syncthreads();
 
     for (int frame = blockIdx.x; frame < P.B; frame += gridDim.x) {
         const IN *src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
@@ -62,8 +69,8 @@ __global__ __launch_bounds__(512) void k_bp(BpParams P)
                     }
                     const R *lrow = (i + 1 == n) ? ch : lm + (size_t)i * N;
                     const R l0 = lrow[j], l1 = lrow[j + s];
-                    const R a = chk<R>(r0, l1 + r1);
-                    const R c = r1 + chk<R>(r0, l0);
+                    const R a = chk_lut<R>(r0, l1 + r1, lut);
+                    const R c = r1 + chk_lut<R>(r0, l0, lut);
                     rm[(size_t)i * N + j] = a;
                     rm[(size_t)i * N + j + s] = c;
                 }
@@ -87,8 +94,8 @@ __global__ __launch_bounds__(512) void k_bp(BpParams P)
                     }
                     const R *lrow = (i + 1 == n) ? ch : lm + (size_t)i * N;
                     const R l0 = lrow[j], l1 = lrow[j + s];
-                    const R a = chk<R>(l0, l1 + r1);
-                    const R c = l1 + chk<R>(r0, l0);
+                    const R a = chk_lut<R>(l0, l1 + r1, lut);
+                    const R c = l1 + chk_lut<R>(r0, l0, lut);
                     if (i > 0) {
                         lm[(size_t)(i - 1) * N + j] = a;
                         lm[(size_t)(i - 1) * N + j + s] = c;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(512) void k_bp(BpParams P)
 template <typename R>
 constexpr size_t bp_lds_bytes(int N, int n)
 {
-    return sizeof(R) * (size_t)N * (1 + 2 * (n - 1)) + sizeof(uint32_t) * (size_t)(N / 32);
+    return sizeof(R) * (size_t)N * (1 + 2 * (n - 1)) + sizeof(uint32_t) * (size_t)(N / 32) + 16 + Lut<R>::bytes;
 }
 
 // ---- error accounting (main()'s compare loop, CASCL_1024_L8.c:296-305) -------------------------------

@@ -1,0 +1,150 @@
+// polar_lut.h -- table-driven form of the reference's 8-level staircase T (SCL_1024.c:352-359) and of the check
+// node CHK (SCL_1024.c:343-374), shared by the tuned SCL kernel and the BP kernel.  Bit-exact by construction:
+// the look-up ends in ONE exact compare against the only threshold that can lie in the operand's cell, and
+// T(s) - T(d) is read from an 8x8 table of the IEEE differences of the table constants.
+#pragma once
+#include "polar_math.h"
+
+namespace polar {
+
+// ---- table-driven staircase -----------------------------------------------------------------------
+// cell(x) for x >= 0: 0 for x < 0.125, 1..48 = 8 cells per binade over [0.125, 8), 49 for x >= 8.
+// The seven thresholds 0.196 .. 4.5 (SCL_1024.c:352-358) fall into seven different cells, so ONE exact
+// compare against the cell's threshold finishes the 8-level look-up.
+// LDS entry (48 bytes): [thr | s_lo s_hi] [thr | d_lo d_hi] [T_lo T_hi], where s_*/d_* are the byte offsets
+// of the row / column of the 8x8 table of differences for "below thr" / "at or above thr".
+template <typename R>
+struct Cell;
+template <>
+struct Cell<double> {
+    static constexpr int BIAS = 0x3FC00000 >> 17;  // cell number of 0.125
+    static __device__ __forceinline__ int raw(double x) { return (int)__builtin_amdgcn_ubfe((unsigned)__double2hiint(x), 17, 14); }
+};
+template <>
+struct Cell<float> {
+    static constexpr int BIAS = 0x3E000000 >> 20;
+    static __device__ __forceinline__ int raw(float x) { return (int)__builtin_amdgcn_ubfe((unsigned)__float_as_int(x), 20, 11); }
+};
+
+template <typename R>
+struct Lut {
+    struct __attribute__((aligned(16))) Q { R thr; int pad_[(8 - sizeof(R)) / 4 + 0]; int lo, hi; };  // {thr @0, lo @8, hi @12}
+    struct __attribute__((aligned(16))) TP { R lo, hi; };
+    static constexpr int NCELL = 50, STRIDE = 48;
+    static constexpr size_t cell_bytes = (size_t)NCELL * STRIDE;
+    static constexpr size_t bytes = cell_bytes + sizeof(R) * 64;
+    unsigned base;  // LDS byte address of the table, pre-biased: entry(x) = base + clamp(raw(x)) * 48
+    const unsigned char *lds0;  // LDS address 0 as a pointer (keeps the address space known)
+    const R *dlt;   // dlt[i*8+j] = T_i - T_j (one IEEE subtraction, like `delta = T(s); delta -= T(d)`)
+
+    static __device__ __forceinline__ int index_of(R x)
+    {
+        const int t = Cell<R>::raw(x);
+        return min(max(t, Cell<R>::BIAS - 1), Cell<R>::BIAS + 48) - (Cell<R>::BIAS - 1);
+    }
+    __device__ __forceinline__ void bind(unsigned char *tab)
+    {
+        lds0 = tab;
+        base = (unsigned)(0 - (Cell<R>::BIAS - 1) * STRIDE);
+        __asm__ volatile("" : "+s"(base));  // opaque: keeps the bias inside the multiply-add, offsets in the ds_read
+        dlt = reinterpret_cast<const R *>(tab + cell_bytes);
+    }
+    typedef int i2 __attribute__((ext_vector_type(2)));
+    // offset selected by the exact compare |x| >= thr of the 16-byte sub-entry {thr @0, (lo, hi) @8} at `sub`
+    __device__ __forceinline__ int pick(R x, unsigned sub) const
+    {
+        const unsigned e = entry(x) + sub;
+        const R thr = *reinterpret_cast<const R *>(lds0 + e);
+        const i2 lh = *reinterpret_cast<const i2 *>(lds0 + e + 8);
+        return (absr(x) >= thr) ? lh.y : lh.x;
+    }
+    // executed by a whole workgroup before its first barrier
+    static __device__ void build(unsigned char *tab, int tid, int nthreads)
+    {
+        R *d = reinterpret_cast<R *>(tab + cell_bytes);
+        const R thr[7] = {R(0.196), R(0.433), R(0.71), R(1.05), R(1.508), R(2.252), R(4.5)};
+        const R tv[8] = {R(0.65), R(0.55), R(0.45), R(0.35), R(0.25), R(0.15), R(0.05), R(0)};
+        for (int i = tid; i < NCELL; i += nthreads) {
+            int b = 0;
+            R t = R(__builtin_huge_val());
+            for (int k = 0; k < 7; ++k) {
+                const int ck = index_of(thr[k]);
+                if (ck < i) ++b;
+                if (ck == i) t = thr[k];
+            }
+            const int b1 = b < 7 ? b + 1 : 7;
+            Q *qs = reinterpret_cast<Q *>(tab + i * STRIDE);
+            Q *qd = reinterpret_cast<Q *>(tab + i * STRIDE + 16);
+            TP *tp = reinterpret_cast<TP *>(tab + i * STRIDE + 32);
+            qs->thr = t; qs->lo = b * 8 * (int)sizeof(R); qs->hi = b1 * 8 * (int)sizeof(R);
+            qd->thr = t; qd->lo = b * (int)sizeof(R); qd->hi = b1 * (int)sizeof(R);
+            tp->lo = tv[b]; tp->hi = tv[b1];
+        }
+        for (int i = tid; i < 64; i += nthreads) d[i] = tv[i >> 3] - tv[i & 7];
+    }
+    // byte offset (from lds0) of the entry of |x|
+    __device__ __forceinline__ unsigned entry(R x) const
+    {
+        const int t = Cell<R>::raw(x);
+        const int c = min(max(t, Cell<R>::BIAS - 1), Cell<R>::BIAS + 48);
+        return __umul24((unsigned)c, (unsigned)STRIDE) + base;
+    }
+    // T(|x|) in one LDS round trip
+    __device__ __forceinline__ R tabv(R x) const
+    {
+        const unsigned e = entry(x);
+        const R thr = *reinterpret_cast<const R *>(lds0 + e);
+        const TP tp = *reinterpret_cast<const TP *>(lds0 + e + 32);
+        return (absr(x) >= thr) ? tp.hi : tp.lo;
+    }
+};
+
+// min(|a|, |b|) in one instruction (the generic fmin lowering canonicalises both operands first)
+__device__ __forceinline__ double minabs(double a, double b)
+{
+    double m;
+    __asm__("v_min_f64 %0, |%1|, |%2|" : "=v"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ float minabs(float a, float b)
+{
+    float m;
+    __asm__("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(m) : "v"(a), "v"(b));
+    return m;
+}
+// m >= 0 with the sign of a*b: (m & 0x7fffffff) | ((a ^ b) & 0x80000000) as one v_bfi
+__device__ __forceinline__ double xor_sign(double m, double a, double b)
+{
+    const unsigned x = (unsigned)(__double2hiint(a) ^ __double2hiint(b));
+    const unsigned hi = (x & 0x80000000u) | (unsigned)__double2hiint(m);  // m >= 0: v_and_or_b32
+    return __hiloint2double((int)hi, __double2loint(m));
+}
+__device__ __forceinline__ float xor_sign(float m, float a, float b)
+{
+    const unsigned x = (unsigned)(__float_as_int(a) ^ __float_as_int(b));
+    return __int_as_float((int)((x & 0x80000000u) | (unsigned)__float_as_int(m)));
+}
+
+// CHK (SCL_1024.c:343-374) with the staircase taken from the tables.  sign(a)sign(b) is applied by
+// xor of the sign bits: for a = -0.0 the reference uses +1, but then min = 0 and delta = +0, and
+// (+-0) + (+0) = +0 either way, so the result is identical.
+template <typename R>
+__device__ __forceinline__ R chk_lut(R a, R b, const Lut<R> &L)
+{
+#ifdef POLAR_DOUBLE_CHK  // timing experiment: marginal cost of one more CHK
+    {
+        const R s2 = b + a * R(1.0000001), d2 = a - b * R(1.0000001);
+        const int o2 = L.pick(s2, 0) + L.pick(d2, 16);
+        const R delta2 = *reinterpret_cast<const R *>(reinterpret_cast<const unsigned char *>(L.dlt) + o2);
+        const R r2 = xor_sign(minabs(s2, d2), a, b) + delta2;
+        __asm__ volatile("" ::"v"(r2));
+    }
+#endif
+    const R s = a + b, d = a - b;
+    const int os = L.pick(s, 0), od = L.pick(d, 16);
+    const R delta = *reinterpret_cast<const R *>(reinterpret_cast<const unsigned char *>(L.dlt) + (os + od));
+    return xor_sign(minabs(a, b), a, b) + delta;
+}
+
+
+}  // namespace polar
