@@ -15,6 +15,7 @@
 
 #include "bp_kernel.h"
 #include "scl_fast.h"
+#include "scl_fast2.h"
 #include "scl_generic.h"
 
 namespace {
@@ -49,6 +50,7 @@ struct polar_ctx {
     std::string last_error;
     std::string kernel_name;
     bool force_generic = false;
+    bool use_fast2 = true;      // POLAR_FAST2=0: one codeword per wavefront (k_scl_fast) instead of two
     bool force_spill = false;   // POLAR_FORCE_SPILL=1: exercise the global-scratch variant on shapes that would fit LDS
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -202,9 +204,37 @@ int launch_fast(polar_ctx *c, const polar::SclParams &P)
     return POLAR_OK;
 }
 
+// two codewords per wavefront (scl_fast2.h), N = 1024, L = 8
+template <typename R, typename IN, bool CRC_ON>
+int launch_fast2(polar_ctx *c, const polar::SclParams &P)
+{
+    using Cfg = polar::Fast2Cfg<R>;
+    auto kern = polar::k_scl_fast2<R, IN, CRC_ON>;
+    constexpr int WAVES = Cfg::WAVES;
+    const size_t lds = Cfg::total;
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WAVES, lds));
+    if (occ < 1) occ = 1;
+    const long long pairs = ((long long)P.B + 1) / 2;
+    long long blocks_needed = (pairs + WAVES - 1) / WAVES;
+    int grid = (int)std::min<long long>(blocks_needed, (long long)occ * c->num_cu);
+    if (grid < 1) grid = 1;
+    polar::SclParams Q = P;
+    const size_t sc_bytes = Cfg::scratch_elems * sizeof(R) * (size_t)grid * WAVES;
+    int rc = ensure(c, c->scratch, sc_bytes);
+    if (rc) return rc;
+    Q.scratch = c->scratch.p;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, c->stream, Q);
+    HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
 template <typename R, typename IN>
 int launch_fast_n(polar_ctx *c, const polar::SclParams &P, bool crc)
 {
+    if (P.N == 1024 && c->use_fast2) return crc ? launch_fast2<R, IN, true>(c, P) : launch_fast2<R, IN, false>(c, P);
     if (P.N == 1024) return crc ? launch_fast<R, IN, 10, true>(c, P) : launch_fast<R, IN, 10, false>(c, P);
     if (P.N == 128) return crc ? launch_fast<R, IN, 7, true>(c, P) : launch_fast<R, IN, 7, false>(c, P);
     return POLAR_ENOKERNEL;
@@ -446,8 +476,10 @@ int polar_create(const polar_cfg *cfg, polar_ctx **out)
     c->kernel_name = nm;
     if (const char *e = getenv("POLAR_FORCE_GENERIC")) c->force_generic = (e[0] == '1');
     if (const char *e = getenv("POLAR_FORCE_SPILL")) c->force_spill = (e[0] == '1');
+    if (const char *e = getenv("POLAR_FAST2")) c->use_fast2 = (e[0] != '0');
     if (fast_ok(c, cfg->dtype == POLAR_F32)) {
-        snprintf(nm, sizeof nm, "k_scl_fast<%s,N=%d,L=8>", cfg->dtype == POLAR_F32 ? "float" : "double", N);
+        snprintf(nm, sizeof nm, "k_scl_fast%s<%s,N=%d,L=8>", (N == 1024 && c->use_fast2) ? "2" : "",
+                 cfg->dtype == POLAR_F32 ? "float" : "double", N);
         c->kernel_name = nm;
     }
     *out = c;

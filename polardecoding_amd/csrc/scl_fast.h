@@ -146,6 +146,12 @@ __device__ __forceinline__ float negmax(float x)
     return m;
 }
 
+#ifdef POLAR_MARKS  // static instruction accounting (tools/count_marks.py): comments in the ISA
+#define POLAR_MARK(name) __asm__ volatile("; MARK " name)
+#else
+#define POLAR_MARK(name) do { } while (0)
+#endif
+
 __device__ __forceinline__ void lds_fence() { __asm__ volatile("" ::: "memory"); }
 
 // negate x when bit 31 of `m` is set (m & 0x80000000 pre-masked): g = cL + (bit ? -cU : cU)
@@ -566,6 +572,7 @@ struct FastDec {
     __device__ __forceinline__ void decide(int o, bool frozen, R lam)
     {
         const int j = 8 * o + K;
+        POLAR_MARK("decide_begin");
         uint32_t crcw = 0;
         if (CRC_ON && !frozen) crcw = crct[j];
         uint32_t bit = 0;
@@ -590,6 +597,7 @@ struct FastDec {
                 ++logact;
             } else {
                 // phase 2 (SCL_1024.c:610-661)
+                POLAR_MARK("phase2_begin");
                 const R c0 = PM + ph0, c1 = PM + ph1;
 #ifdef POLAR_DOUBLE_RANK
                 {
@@ -598,6 +606,7 @@ struct FastDec {
                 }
 #endif
                 const uint32_t mask = survivors(c0, c1);
+                POLAR_MARK("rank_end");
                 const uint32_t m0 = mask & 0xFFu, m1 = mask >> 8;
                 const uint32_t m_both = m0 & m1, m_dead = ~(m0 | m1) & 0xFFu;
                 if (__popc(mask) < L) fl |= 0x1u;  // median tie ("Oops!", :621-622)
@@ -606,6 +615,7 @@ struct FastDec {
                     bit = (!s0 && s1) ? 1u : 0u;  // every slot keeps exactly one branch: no copy
                     PM = bit ? c1 : c0;
                 } else {
+                    POLAR_MARK("fork_begin");
                     // m-th both-survivor (ascending slot) forks into the m-th dead slot (:636-661)
                     const bool dead = !s0 && !s1;
                     const int myrank = __popc(m_dead & ((1u << p) - 1u));
@@ -638,9 +648,12 @@ struct FastDec {
                     else { bit = 0; PM = c0; }  // tie rule: un-refilled dead slot continues as its 0-branch
                 }
             }
+            POLAR_MARK("fork_end");
             if (CRC_ON) crc ^= bit ? crcw : 0u;
         }
+        POLAR_MARK("setbit_begin");
         set_bit_k<K>(o, bit);
+        POLAR_MARK("decide_end");
     }
 
     // ---- octets whose first seven leaves are frozen (patterns 0xFF, 0x7F) ----

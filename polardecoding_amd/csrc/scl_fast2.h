@@ -1,0 +1,586 @@
+// scl_fast2.h -- CA-SCL / SCL, L = 8, N = 1024: TWO codewords per wavefront.
+//
+// k_scl_fast (scl_fast.h) is VALU-issue bound at 4 waves/SIMD, and most of its instructions -- the three
+// narrowest LLR levels and the whole per-leaf decision (PHI, candidate ranking, fork bookkeeping) -- carry
+// useful data in 8 of 64 lanes.  Here a path owns 4 lanes instead of 8 and the other half of every 8-lane
+// path group belongs to a second, independent codeword:
+//
+//     lane = p*8 + c*4 + pos        p = path slot 0..7, c = codeword 0/1, pos = 0..3
+//
+// so every narrow-level and decision instruction serves two codewords.  Level t >= 2 holds 2^t/4 registers
+// per lane (element e = pos + 4r, level t at A[2^t/4 ...]); levels 7, 8, the top-left level and the channel
+// vector are in the per-wave global scratch / the input exactly as in k_scl_fast.  Everything that was
+// wave-uniform scalar logic there and differs per codeword (survivor masks, fork matching) is per-lane here;
+// the leaf schedule (frozen pattern) is the same for both codewords, so control flow stays uniform.
+// Arithmetic is the same as k_scl_fast / the reference, operation for operation.
+#pragma once
+#include "scl_fast.h"
+
+namespace polar {
+
+template <typename R>
+struct Fast2Cfg {
+    static constexpr int NLOG = 10, N = 1024, NW = 32, TOP = 9, HI = 8, L = 8;
+    static constexpr int NA = 32;   // levels 2..6, level t at offset 2^t/4
+    static constexpr int WAVES = 4;
+    static constexpr int MIN_WAVES_PER_SIMD = 3;
+    static constexpr int NFA = HI - 3;  // pointer fields: LLR levels 4..8, then partial-sum levels 5..9
+    // per-codeword scratch (elements of R)
+    static constexpr size_t sc_l8 = 0;
+    static constexpr size_t sc_l7 = sc_l8 + 8 * 256;
+    static constexpr size_t sc_l6 = sc_l7 + 8 * 128;
+    static constexpr size_t sc_tl = sc_l6 + 8 * 64;
+    static constexpr size_t scratch_cw = sc_tl + 512;
+    static constexpr size_t scratch_elems = 2 * scratch_cw;  // per wave
+    // block-shared LDS
+    static constexpr size_t off_lut = 0;
+    static constexpr size_t off_frz = off_lut + ((Lut<R>::bytes + 15) / 16) * 16;
+    static constexpr size_t off_crc = off_frz + 4 * NW;
+    static constexpr size_t off_kth = off_crc + 4 * N;      // kth[mask][k] = index of the k-th set bit of mask (u8)
+    static constexpr size_t shared_bytes = off_kth + 256 * 8;
+    // per-wave LDS
+    static constexpr size_t off_bl = 0;                        // saved partial sums [2][8][NW]
+    static constexpr size_t off_cw = off_bl + 4 * 2 * 8 * NW;  // working partial sums [2][8][NW]
+    static constexpr size_t off_cd = off_cw + 4 * 2 * 8 * NW;  // candidates [2][16]
+    static constexpr size_t off_ky = off_cd + sizeof(R) * 32;  // keys [2][16]
+    static constexpr size_t per_wave = off_ky + 128;
+    static constexpr size_t total = shared_bytes + WAVES * per_wave;
+};
+
+template <int QP>
+__device__ __forceinline__ double quadp(double x) { return quad_lanes<QP>(x); }
+template <int QP>
+__device__ __forceinline__ float quadp(float x) { return quad_lanes<QP>(x); }
+
+template <typename R, typename IN, bool CRC_ON>
+struct Fast2Dec {
+    using C = Fast2Cfg<R>;
+    static constexpr int N = C::N, NW = C::NW, TOP = C::TOP, HI = C::HI, L = 8, NFA = C::NFA;
+
+    R A[C::NA];      // levels 2..6
+    R a1;            // level 1 (pos 0, 1)
+    R PM;            // valid at pos 0
+    uint32_t ptr, crc, bl0, fl;
+    int logact;
+    int p, c, pos, lane, gl;   // gl = c*4 + pos: lane offset inside a path group
+    int own_addr, oth_addr;    // rank network: byte addresses into keys[]
+    int cand_addr;
+    Lut<R> lut;
+    R *cand;
+    uint32_t *blw, *curw, *keys;   // this lane's codeword slice of the per-wave arrays
+    const uint32_t *crct;
+    const unsigned char *kth;
+    R *scr;          // this codeword's scratch
+    const IN *src;   // this codeword's input row
+    double sigma;
+
+    __device__ __forceinline__ int pa(int t) const { return (ptr >> (3 * (t - 4))) & 7; }
+    __device__ __forceinline__ void set_pa(int t, int v) { ptr = (ptr & ~(7u << (3 * (t - 4)))) | ((uint32_t)v << (3 * (t - 4))); }
+    __device__ __forceinline__ int pb(int t) const { return (ptr >> (3 * (NFA + t - 5))) & 7; }
+    __device__ __forceinline__ void set_pb(int t, int v) { ptr = (ptr & ~(7u << (3 * (NFA + t - 5)))) | ((uint32_t)v << (3 * (NFA + t - 5))); }
+    __device__ __forceinline__ R chk(R a, R b) const { return chk_lut<R>(a, b, lut); }
+    __device__ __forceinline__ R chv(int e) const
+    {
+        double v = (double)src[e];
+        if (sigma > 0) v = llr_from_y(v, sigma);
+        return (R)v;
+    }
+    __device__ __forceinline__ R *l8(int slot) const { return scr + C::sc_l8 + slot * 256; }
+    __device__ __forceinline__ R *l7(int slot) const { return scr + C::sc_l7 + slot * 128; }
+    __device__ __forceinline__ R *l6s(int slot) const { return scr + C::sc_l6 + slot * 64; }
+    __device__ __forceinline__ R *tls() const { return scr + C::sc_tl; }
+
+    // ---- register levels: f on own data ----
+    template <int T>  // T in [2, 5]: level T from level T+1
+    __device__ __forceinline__ void f_reg()
+    {
+        constexpr int RO = (1 << T) / 4;
+#pragma unroll
+        for (int r = 0; r < RO; ++r) A[RO + r] = chk(A[2 * RO + r], A[3 * RO + r]);
+        if constexpr (T >= 4) set_pa(T, p);
+    }
+    // ---- register levels: g from the owner's level T+1 (bpermute), T in {4, 5} ----
+    template <int T>
+    __device__ __forceinline__ void g_reg()
+    {
+        constexpr int RO = (1 << T) / 4;
+        const int sl = pa(T + 1) * 8 + gl;
+        uint32_t w;
+        if constexpr (T == 5) w = blw[pb(5) * NW + 1] >> pos;   // level 5: word 1, bit e = pos + 4r
+        else w = bl0 >> (16 + pos);                              // level 4: bits 16 + e
+#pragma unroll
+        for (int r = 0; r < RO; ++r) {
+            const R x = __shfl(A[2 * RO + r], sl), y = __shfl(A[3 * RO + r], sl);
+            A[RO + r] = g_bit<R>(x, y, w, 4 * r);
+        }
+        set_pa(T, p);
+    }
+    __device__ __forceinline__ void g3()  // level 3 (eager) from the owner's level 4
+    {
+        const int sl = pa(4) * 8 + gl;
+        const uint32_t w = bl0 >> (8 + pos);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const R x = __shfl(A[4 + r], sl), y = __shfl(A[6 + r], sl);
+            A[2 + r] = g_bit<R>(x, y, w, 4 * r);
+        }
+    }
+
+    // ---- scratch levels ----
+    __device__ __forceinline__ void load_l6()
+    {
+        vm_drain();
+        const R *q = l6s(p) + pos;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) A[16 + r] = ld_sc(q + 4 * r);
+        set_pa(6, p);
+    }
+    // d >= 8 (octets 0, 32, 64, 96): level 8 from the top level (f, or g when gstep), f down to level 6.
+    // Pass rr: level-8 elements e0 + 64k (k < 4), level-7 elements e0, e0 + 64, level-6 element e0 = pos + 4 rr.
+    __device__ __forceinline__ void from_top(bool right, bool gstep)
+    {
+        vm_drain();
+        const uint32_t *bt = blw + pb(TOP) * NW + 16;  // beta_9: words 16..31
+        const uint32_t *bh = blw + pb(HI) * NW + 8;    // beta_8: words 8..15
+        const R *t = tls();
+        R *o8 = l8(p), *o7 = l7(p), *o6 = l6s(p);
+        for (int rr = 0; rr < 16; ++rr) {
+            const int e0 = pos + 4 * rr;
+            const int sh = 4 * (rr & 7);
+            const int wq = rr >> 3;
+            R v8[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + 64 * k;
+                R x, y;
+                if (right) {
+                    const uint32_t w0 = bt[2 * k + wq] >> pos, w1 = bt[8 + 2 * k + wq] >> pos;
+                    x = g_bit<R>(chv(e), chv(e + 512), w0, sh);
+                    y = g_bit<R>(chv(e + 256), chv(e + 768), w1, sh);
+                } else {
+                    x = ld_sc(t + e);
+                    y = ld_sc(t + e + 256);
+                }
+                if (gstep) v8[k] = g_bit<R>(x, y, bh[2 * k + wq] >> pos, sh);
+                else v8[k] = chk(x, y);
+                o8[e] = v8[k];
+            }
+            const R v70 = chk(v8[0], v8[2]), v71 = chk(v8[1], v8[3]);
+            o7[e0] = v70;
+            o7[e0 + 64] = v71;
+            o6[e0] = chk(v70, v71);
+        }
+        set_pa(8, p);
+        set_pa(7, p);
+        load_l6();
+    }
+    __device__ __forceinline__ void from_l8()  // d == 7
+    {
+        vm_drain();
+        const R *s8 = l8(pa(8));
+        const uint32_t *b7 = blw + pb(7) * NW + 4;  // beta_7: words 4..7
+        R *o7 = l7(p), *o6 = l6s(p);
+        for (int rr = 0; rr < 16; ++rr) {
+            const int e0 = pos + 4 * rr;
+            const int sh = 4 * (rr & 7);
+            const int wq = rr >> 3;
+            const R x0 = ld_sc(s8 + e0), x1 = ld_sc(s8 + e0 + 64), x2 = ld_sc(s8 + e0 + 128), x3 = ld_sc(s8 + e0 + 192);
+            const R v70 = g_bit<R>(x0, x2, b7[wq] >> pos, sh);
+            const R v71 = g_bit<R>(x1, x3, b7[2 + wq] >> pos, sh);
+            o7[e0] = v70;
+            o7[e0 + 64] = v71;
+            o6[e0] = chk(v70, v71);
+        }
+        set_pa(7, p);
+        load_l6();
+    }
+    __device__ __forceinline__ void from_l7()  // d == 6
+    {
+        vm_drain();
+        const R *s7 = l7(pa(7)) + pos;
+        const uint32_t *b6 = blw + pb(6) * NW + 2;  // beta_6: words 2, 3
+        const uint32_t w0 = b6[0] >> pos, w1 = b6[1] >> pos;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const R x = ld_sc(s7 + 4 * r), y = ld_sc(s7 + 4 * r + 64);
+            A[16 + r] = g_bit<R>(x, y, r < 8 ? w0 : w1, 4 * (r & 7));
+        }
+        set_pa(6, p);
+    }
+
+    // head of octet o: g at level d = ctz(8o) (root f for o = 0), f chain down to level 3 (A[2], A[3])
+    __device__ __forceinline__ void octet_head(int o)
+    {
+        const int d = (o == 0) ? 10 : 3 + __builtin_ctz((unsigned)o);
+        if (d >= 8) from_top(/*right=*/o >= N / 16, /*gstep=*/d == 8);
+        else if (d == 7) from_l8();
+        else if (d == 6) from_l7();
+        else if (d == 5) g_reg<5>();
+        else if (d == 4) g_reg<4>();
+        else g3();
+        if (d > 5) f_reg<5>();
+        if (d > 4) f_reg<4>();
+        if (d > 3) f_reg<3>();
+    }
+
+    // ---- partial sums (identical per path to k_scl_fast) ----
+    template <int K>
+    __device__ __forceinline__ void set_bit_k(int o, uint32_t bit)
+    {
+        if constexpr ((K & 1) == 0) {
+            bl0 = (bl0 & ~2u) | (bit << 1);
+        } else if constexpr ((K & 3) == 1) {
+            const uint32_t c1 = (((bl0 >> 1) & 1u) ^ bit) | (bit << 1);
+            bl0 = (bl0 & ~0xCu) | (c1 << 2);
+        } else if constexpr (K == 3) {
+            const uint32_t c1 = (((bl0 >> 1) & 1u) ^ bit) | (bit << 1);
+            const uint32_t c2 = (((bl0 >> 2) & 3u) ^ c1) | (c1 << 2);
+            bl0 = (bl0 & ~0xF0u) | (c2 << 4);
+        } else {
+            set_bit_tail(8 * o + 7, bit);
+        }
+    }
+    __device__ __forceinline__ void set_bit_tail(int j, uint32_t bit)
+    {
+        uint32_t cur = bit;
+        const int z = __builtin_ctz(~(unsigned)j);
+        const int zl = z < 5 ? z : 5;
+        for (int t = 0; t < zl; ++t) {
+            const int h = 1 << t;
+            const uint32_t mask = (1u << h) - 1u;
+            const uint32_t l = (bl0 >> h) & mask;
+            cur = (l ^ (cur & mask)) | ((cur & mask) << h);
+        }
+        if (z < 5) {
+            const int h = 1 << z;
+            const uint32_t mask = (1u << h) - 1u;
+            bl0 = (bl0 & ~(mask << h)) | ((cur & mask) << h);
+            return;
+        }
+        lds_fence();
+        if (pos == 0) curw[p * NW] = cur;
+        lds_fence();
+        int t = 5;
+        while (t < 10 && ((j >> t) & 1)) {
+            const int nw = 1 << (t - 5);
+            const int sb = pb(t);
+            for (int w = pos; w < nw; w += 4) {
+                const uint32_t cc = curw[p * NW + w];
+                const uint32_t l = blw[sb * NW + nw + w];
+                curw[p * NW + w] = l ^ cc;
+                curw[p * NW + w + nw] = cc;
+            }
+            lds_fence();
+            ++t;
+        }
+        if (t < 10) {
+            const int nw = 1 << (t - 5);
+            for (int w = pos; w < nw; w += 4) blw[p * NW + nw + w] = curw[p * NW + w];
+            set_pb(t, p);
+            lds_fence();
+        }
+    }
+
+    // ---- survivors (SCL_1024.c:612-633) for both codewords; returns this lane's codeword's 16-bit mask ----
+    // Rows 0,1 of the wave rank codeword 0, rows 2,3 codeword 1: row h of a pair compares its 16 keys with the
+    // row rotated by 8h .. 8h+7; permlane16_swap adds the two partial counts.
+    __device__ __forceinline__ uint32_t survivors(R c0, R c1)
+    {
+        lds_fence();
+        if (pos == 0) {
+            keys[2 * p] = metric_key(c0);
+            keys[2 * p + 1] = metric_key(c1);
+        }
+        lds_fence();
+        const unsigned char *kb = reinterpret_cast<const unsigned char *>(keys) - 64 * c;  // wave base of keys[2][16]
+        const uint32_t own = *reinterpret_cast<const uint32_t *>(kb + own_addr);
+        const uint32_t oth = *reinterpret_cast<const uint32_t *>(kb + oth_addr);
+        uint32_t cnt = (oth <= own) ? 1u : 0u;
+        cnt += ((uint32_t)dpp_i<0x121>((int)oth) <= own) ? 1u : 0u;
+        cnt += ((uint32_t)dpp_i<0x122>((int)oth) <= own) ? 1u : 0u;
+        cnt += ((uint32_t)dpp_i<0x123>((int)oth) <= own) ? 1u : 0u;
+        cnt += ((uint32_t)dpp_i<0x124>((int)oth) <= own) ? 1u : 0u;
+        cnt += ((uint32_t)dpp_i<0x125>((int)oth) <= own) ? 1u : 0u;
+        cnt += ((uint32_t)dpp_i<0x126>((int)oth) <= own) ? 1u : 0u;
+        cnt += ((uint32_t)dpp_i<0x127>((int)oth) <= own) ? 1u : 0u;
+        {
+            auto r = __builtin_amdgcn_permlane16_swap(cnt, cnt, false, false);
+            cnt = r[0] + r[1];
+        }
+        uint64_t b = __ballot(cnt <= (uint32_t)L);
+        uint32_t m_a = (uint32_t)b & 0xFFFFu, m_b = (uint32_t)(b >> 32) & 0xFFFFu;
+        if (sizeof(R) == 8 && (__popc(m_a) != L || __popc(m_b) != L)) {
+            // a key tie across the boundary (or a true median tie) in either codeword: decide on the full metrics
+            lds_fence();
+            if (pos == 0) {
+                cand[p] = c0;
+                cand[8 + p] = c1;
+            }
+            lds_fence();
+            const R *cb = reinterpret_cast<const R *>(reinterpret_cast<const unsigned char *>(cand) - (int)sizeof(R) * 16 * c);
+            const R *mycand = reinterpret_cast<const R *>(reinterpret_cast<const unsigned char *>(cb) + cand_addr);
+            const R mine = mycand[lane & 15];
+            int n = 0;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) n += (mycand[m] <= mine) ? 1 : 0;
+            b = __ballot(n <= L);
+            m_a = (uint32_t)b & 0xFFFFu;
+            m_b = (uint32_t)(b >> 32) & 0xFFFFu;
+        }
+        return c ? m_b : m_a;
+    }
+
+    // ---- decision at leaf j = 8o + K; lambda valid at pos 0 ----
+    template <int K>
+    __device__ __forceinline__ void decide(int o, bool frozen, R lam)
+    {
+        const int j = 8 * o + K;
+        uint32_t crcw = 0;
+        if (CRC_ON && !frozen) crcw = crct[j];
+        uint32_t bit = 0;
+        const R tt = lut.tabv(lam);
+        const R ph0 = tt + negmax(lam);  // PHI(.,0)
+        if (frozen) {
+            PM += ph0;
+        } else {
+            const R ph1 = tt + posmax(lam);  // PHI(.,1)
+            if (logact < 3) {
+                bit = (p >> logact) & 1;
+                PM += bit ? ph1 : ph0;
+                ++logact;
+            } else {
+                const R c0 = PM + ph0, c1 = PM + ph1;
+                const uint32_t mask = survivors(c0, c1);
+                const uint32_t m0 = mask & 0xFFu, m1 = mask >> 8;
+                const uint32_t m_both = m0 & m1, m_dead = ~(m0 | m1) & 0xFFu;
+                if (__popc(mask) < L) fl |= 0x1u;  // median tie in this lane's codeword
+                const bool s0 = (m0 >> p) & 1, s1 = (m1 >> p) & 1;
+                if (__ballot(m_dead != 0u) == 0ull) {
+                    bit = (!s0 && s1) ? 1u : 0u;  // no codeword forks: every slot keeps exactly one branch
+                    PM = bit ? c1 : c0;
+                } else {
+                    // m-th both-survivor (ascending slot) forks into the m-th dead slot (:636-661), per codeword
+                    const bool dead = !s0 && !s1;
+                    const int myrank = __popc(m_dead & ((1u << p) - 1u));
+                    const bool refilled = dead && (myrank < __popc(m_both));
+                    const int sg = refilled ? (int)kth[m_both * 8 + myrank] : p;
+                    const int sl = sg * 8 + gl;
+                    const R c1s = __shfl(c1, sl);
+                    ptr = __shfl(ptr, sl);
+                    crc = __shfl(crc, sl);
+                    bl0 = __shfl(bl0, sl);
+                    if constexpr ((K & 4) == 0) { A[2] = __shfl(A[2], sl); A[3] = __shfl(A[3], sl); }  // level 3, read by g2
+                    if constexpr ((K & 2) == 0) A[1] = __shfl(A[1], sl);                                // level 2, read by g1
+                    if constexpr ((K & 1) == 0) a1 = __shfl(a1, sl);                                    // level 1, read by g0
+                    if (refilled) { bit = 1; PM = c1s; }
+                    else if (s0) { bit = 0; PM = c0; }
+                    else if (s1) { bit = 1; PM = c1; }
+                    else { bit = 0; PM = c0; }  // tie rule: un-refilled dead slot continues as its 0-branch
+                }
+            }
+            if (CRC_ON) crc ^= bit ? crcw : 0u;
+        }
+        set_bit_k<K>(o, bit);
+    }
+
+    // ---- octets whose first seven leaves are frozen: breadth-first (all partner bits are 0) ----
+    __device__ __forceinline__ void octet_frozen_prefix(int o, bool last_frozen)
+    {
+        // level 2: f half (leaves 0..3) and g half (leaves 4..7), element pos each
+        R xf = chk(A[2], A[3]), xg = A[3] + A[2];
+        // level 1: lanes pos 0,1 = f results, lanes 2,3 = g results, for both halves
+        R yf = quadp<0x4E>(xf), yg = quadp<0x4E>(xg);  // lane ^ 2
+        {
+            const R ff = chk(xf, yf), gf = xf + yf, fg = chk(xg, yg), gg = xg + yg;
+            xf = (pos & 2) ? gf : ff;
+            xg = (pos & 2) ? gg : fg;
+        }
+        // level 0: lambda_k in lane pos = k & 3 of (k < 4 ? xf : xg)
+        yf = quadp<0xB1>(xf); yg = quadp<0xB1>(xg);    // lane ^ 1
+        R lf, lg;
+        {
+            const R ff = chk(xf, yf), gf = xf + yf, fg = chk(xg, yg), gg = xg + yg;
+            lf = (pos & 1) ? gf : ff;
+            lg = (pos & 1) ? gg : fg;
+        }
+        const R pf = lut.tabv(lf) + negmax(lf), pg = lut.tabv(lg) + negmax(lg);  // PHI(lambda_k, 0)
+        PM += pf;
+        PM += quadp<0x55>(pf);  // lane 1 of the quad
+        PM += quadp<0xAA>(pf);  // lane 2
+        PM += quadp<0xFF>(pf);  // lane 3
+        PM += pg;
+        PM += quadp<0x55>(pg);
+        PM += quadp<0xAA>(pg);
+        bl0 &= ~0xFEu;
+        if (last_frozen) {
+            PM += quadp<0xFF>(pg);
+            set_bit_tail(8 * o + 7, 0u);
+        } else {
+            decide<7>(o, false, quadp<0xFF>(lg));
+        }
+    }
+
+    // ---- the 8 leaves of octet o; A[2], A[3] hold the level-3 LLRs ----
+    __device__ __forceinline__ void octet(int o, uint32_t fm)
+    {
+        // leaf 0: f2 f1 f0
+        A[1] = chk(A[2], A[3]);
+        a1 = chk(A[1], quadp<0x4E>(A[1]));
+        decide<0>(o, fm & 1, chk(a1, quadp<0xB1>(a1)));
+        // leaf 1: g0
+        decide<1>(o, (fm >> 1) & 1, g_bit<R>(a1, quadp<0xB1>(a1), bl0, 1));
+        // leaf 2: g1 f0
+        a1 = g_bit<R>(A[1], quadp<0x4E>(A[1]), bl0, 2 + pos);
+        decide<2>(o, (fm >> 2) & 1, chk(a1, quadp<0xB1>(a1)));
+        // leaf 3: g0
+        decide<3>(o, (fm >> 3) & 1, g_bit<R>(a1, quadp<0xB1>(a1), bl0, 1));
+        // leaf 4: g2 f1 f0
+        A[1] = g_bit<R>(A[2], A[3], bl0, 4 + pos);
+        a1 = chk(A[1], quadp<0x4E>(A[1]));
+        decide<4>(o, (fm >> 4) & 1, chk(a1, quadp<0xB1>(a1)));
+        // leaf 5: g0
+        decide<5>(o, (fm >> 5) & 1, g_bit<R>(a1, quadp<0xB1>(a1), bl0, 1));
+        // leaf 6: g1 f0
+        a1 = g_bit<R>(A[1], quadp<0x4E>(A[1]), bl0, 2 + pos);
+        decide<6>(o, (fm >> 6) & 1, chk(a1, quadp<0xB1>(a1)));
+        // leaf 7: g0
+        decide<7>(o, (fm >> 7) & 1, g_bit<R>(a1, quadp<0xB1>(a1), bl0, 1));
+    }
+};
+
+template <typename R, typename IN, bool CRC_ON>
+__global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_fast2(SclParams P)
+{
+    using D = Fast2Dec<R, IN, CRC_ON>;
+    using C = Fast2Cfg<R>;
+    constexpr int N = C::N, NW = C::NW, L = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = threadIdx.x >> 6;
+    unsigned char *base = smem + C::shared_bytes + (size_t)wave * C::per_wave;
+    uint32_t *frz = reinterpret_cast<uint32_t *>(smem + C::off_frz);
+    uint32_t *crct = reinterpret_cast<uint32_t *>(smem + C::off_crc);
+    unsigned char *kth = smem + C::off_kth;
+
+    Lut<R>::build(smem + C::off_lut, threadIdx.x, blockDim.x);
+    for (int i = threadIdx.x; i < NW; i += blockDim.x) frz[i] = P.frozen[i];
+    if (CRC_ON)
+        for (int i = threadIdx.x; i < N; i += blockDim.x) crct[i] = P.crc_tab[i];
+    for (int i = threadIdx.x; i < 256 * 8; i += blockDim.x) {
+        int m = i >> 3, k = i & 7, idx = 0, seen = 0;
+        for (int b = 0; b < 8; ++b)
+            if ((m >> b) & 1) {
+                if (seen == k) idx = b;
+                ++seen;
+            }
+        kth[i] = (unsigned char)idx;
+    }
+    __syncthreads();
+
+    D s;
+    s.lane = threadIdx.x & 63;
+    s.p = s.lane >> 3;
+    s.c = (s.lane >> 2) & 1;
+    s.pos = s.lane & 3;
+    s.gl = s.lane & 7;
+    s.lut.bind(smem + C::off_lut);
+    s.crct = crct;
+    s.kth = kth;
+    s.blw = reinterpret_cast<uint32_t *>(base + C::off_bl) + s.c * 8 * NW;
+    s.curw = reinterpret_cast<uint32_t *>(base + C::off_cw) + s.c * 8 * NW;
+    s.cand = reinterpret_cast<R *>(base + C::off_cd) + s.c * 16;
+    s.keys = reinterpret_cast<uint32_t *>(base + C::off_ky) + s.c * 16;
+    s.sigma = P.sigma;
+    {   // rank network: lane (row, i): rows 0,1 -> codeword 0, rows 2,3 -> codeword 1; candidate i is
+        // (slot i & 7, branch i >> 3) stored at keys[cw][2*slot + branch]
+        const int i = s.lane & 15, row = s.lane >> 4, cwr = row >> 1, h = row & 1;
+        const int jj = (i + 8 * h) & 15;
+        s.own_addr = 64 * cwr + 4 * (2 * (i & 7) + (i >> 3));
+        s.oth_addr = 64 * cwr + 4 * (2 * (jj & 7) + (jj >> 3));
+        s.cand_addr = (int)sizeof(R) * 16 * cwr;
+    }
+    const int lane = s.lane, p = s.p, c = s.c, pos = s.pos;
+    const int wave_global = blockIdx.x * C::WAVES + wave;
+    const int waves_total = gridDim.x * C::WAVES;
+    R *scr_wave = reinterpret_cast<R *>(P.scratch) + (size_t)wave_global * C::scratch_elems;
+    s.scr = scr_wave + (size_t)c * C::scratch_cw;
+
+    for (int pair = wave_global; 2 * pair < P.B; pair += waves_total) {
+        const int frame_raw = 2 * pair + c;
+        const bool live = frame_raw < P.B;
+        const int frame = live ? frame_raw : P.B - 1;  // odd tail: the idle half re-decodes the last frame, no store
+        s.src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
+        {   // root f, single path per codeword: lanes of codeword c are w = p*4 + pos = 0..31
+            R *t = s.tls();
+            const int w = p * 4 + pos;
+#pragma unroll 2
+            for (int e = w; e < N / 2; e += 32) t[e] = s.chk(s.chv(e), s.chv(e + N / 2));
+        }
+        for (int w = lane; w < 2 * 8 * NW; w += 64) (s.blw - c * 8 * NW)[w] = 0;
+        lds_fence();
+
+        s.PM = R(0);
+        s.ptr = 0;
+        for (int t = 4; t <= 8; ++t) s.set_pa(t, p);
+        for (int t = 5; t <= 9; ++t) s.set_pb(t, p);
+        s.crc = 0;
+        s.bl0 = 0;
+        s.a1 = R(0);
+#pragma unroll
+        for (int r = 0; r < C::NA; ++r) s.A[r] = R(0);
+        s.fl = 0;
+        s.logact = 0;
+        uint32_t fword = 0;
+
+        for (int o = 0; o < N / 8; ++o) {
+            if ((o & 3) == 0) fword = frz[o >> 2];
+            s.octet_head(o);
+            const uint32_t fm = (fword >> (8 * (o & 3))) & 0xFFu;
+            if ((fm & 0x7Fu) == 0x7Fu) s.octet_frozen_prefix(o, fm == 0xFFu);
+            else s.octet(o, fm);
+        }
+
+        // ---- choose the path, per codeword (SCL_1024.c:667-674; CASCL_1024_L8.c:725-755) ----
+        const bool pass = CRC_ON && (s.crc == 0);
+        const uint64_t bp_ = __ballot(pass && pos == 0);
+        // lanes of codeword c at pos 0 are lanes p*8 + 4c: bits 4c, 8+4c, ...
+        const uint64_t cwmask = 0x0101010101010101ull << (4 * c);
+        const bool any = (bp_ & cwmask) != 0ull;
+        int best = -1;
+        R best_pm = R(0);
+        for (int q = 0; q < L; ++q) {
+            const R pq = __shfl(s.PM, q * 8 + 4 * c);
+            const int okq = __shfl((int)(any ? pass : true), q * 8 + 4 * c);
+            if (okq && (best < 0 || pq < best_pm)) {
+                best = q;
+                best_pm = pq;
+            }
+        }
+        uint32_t fl = s.fl;
+        if (any) fl |= 0x2u;
+        // x_hat = root partial sums of the winner; u_hat = x_hat F^{(x)n}; word index w = p*4 + pos per codeword
+        lds_fence();
+        {
+            const int w = p * 4 + pos;
+            uint32_t x = s.curw[best * NW + w];
+            x ^= (x >> 1) & 0x55555555u;
+            x ^= (x >> 2) & 0x33333333u;
+            x ^= (x >> 4) & 0x0F0F0F0Fu;
+            x ^= (x >> 8) & 0x00FF00FFu;
+            x ^= (x >> 16) & 0x0000FFFFu;
+#pragma unroll
+            for (int hw = 1; hw < NW; hw <<= 1) {
+                const int wo = w ^ hw;  // partner word; the lower one of the pair absorbs the upper one
+                const uint32_t ov = __shfl(x, (wo >> 2) * 8 + 4 * c + (wo & 3));
+                if (!(w & hw)) x ^= ov;
+            }
+            if (live) P.out_bits[(size_t)frame * NW + w] = x;
+        }
+        if (live && p == 0 && pos == 0) {
+            if (P.pm) P.pm[frame] = (double)best_pm;
+            if (P.flags) P.flags[frame] = fl;
+        }
+        lds_fence();
+    }
+}
+
+}  // namespace polar
