@@ -152,6 +152,21 @@ def main():
     except Exception:
         traffic = None
 
+    # secondary figure (not `value`): the f32 instantiation of the same kernel on the same batch, kernel-timed
+    secondary = None
+    if rank == 0 and args.dtype == "f64":
+        try:
+            dec32 = pa.CASCL(N, K, L=8, crc_taps=CRC, dtype=pa.F32, device=local)
+            dec32.use_torch_stream()
+            llr32 = batches[0][0].float().contiguous()
+            dec32.decode_device(llr32, out_bits=out_bits)
+            torch.cuda.synchronize()
+            ms32 = dec32.time_decode_device(llr32, out_bits, 3)
+            secondary = {"dtype": "f32", "frames_per_s_one_gpu": B / ms32 * 1e3, "kernel": dec32.kernel_name,
+                         "note": "same operation order in binary32: FER-equivalent, not bit-identical to the reference"}
+        except Exception as e:  # pragma: no cover
+            secondary = {"error": str(e)}
+
     if rank == 0:
         total_frames = world * B * args.steps
         value = total_frames / elapsed
@@ -179,6 +194,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "path is VALU/LDS-bound, not HBM-bound (SURVEY.md 0.5); see DESIGN.md"},
         }
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.snr)
         print(json.dumps(out), flush=True)

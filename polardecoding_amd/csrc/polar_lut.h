@@ -32,7 +32,13 @@ struct Lut {
     struct __attribute__((aligned(16))) TP { R lo, hi; };
     static constexpr int NCELL = 50, STRIDE = 48;
     static constexpr size_t cell_bytes = (size_t)NCELL * STRIDE;
-    static constexpr size_t bytes = cell_bytes + sizeof(R) * 64;
+    static constexpr size_t copy_bytes = cell_bytes + sizeof(R) * 64;   // one copy: cells + 8x8 differences
+#ifndef POLAR_LUT_COPIES
+#define POLAR_LUT_COPIES 1
+#endif
+    // COPIES > 1: lane l uses copy l % COPIES, which spreads the random cell reads over more LDS banks
+    static constexpr int COPIES = POLAR_LUT_COPIES;
+    static constexpr size_t bytes = copy_bytes * COPIES;
     unsigned base;  // LDS byte address of the table, pre-biased: entry(x) = base + clamp(raw(x)) * 48
     const unsigned char *lds0;  // LDS address 0 as a pointer (keeps the address space known)
     const R *dlt;   // dlt[i*8+j] = T_i - T_j (one IEEE subtraction, like `delta = T(s); delta -= T(d)`)
@@ -44,9 +50,11 @@ struct Lut {
     }
     __device__ __forceinline__ void bind(unsigned char *tab)
     {
+        if (COPIES > 1) tab += (size_t)(threadIdx.x % COPIES) * copy_bytes;
         lds0 = tab;
         base = (unsigned)(0 - (Cell<R>::BIAS - 1) * STRIDE);
-        __asm__ volatile("" : "+s"(base));  // opaque: keeps the bias inside the multiply-add, offsets in the ds_read
+        if (COPIES == 1) __asm__ volatile("" : "+s"(base));  // opaque: keeps the bias inside the multiply-add
+        else __asm__ volatile("" : "+v"(base));
         dlt = reinterpret_cast<const R *>(tab + cell_bytes);
     }
     typedef int i2 __attribute__((ext_vector_type(2)));
@@ -59,8 +67,10 @@ struct Lut {
         return (absr(x) >= thr) ? lh.y : lh.x;
     }
     // executed by a whole workgroup before its first barrier
-    static __device__ void build(unsigned char *tab, int tid, int nthreads)
+    static __device__ void build(unsigned char *tab0, int tid, int nthreads)
     {
+      for (int cp = 0; cp < COPIES; ++cp) {
+        unsigned char *tab = tab0 + (size_t)cp * copy_bytes;
         R *d = reinterpret_cast<R *>(tab + cell_bytes);
         const R thr[7] = {R(0.196), R(0.433), R(0.71), R(1.05), R(1.508), R(2.252), R(4.5)};
         const R tv[8] = {R(0.65), R(0.55), R(0.45), R(0.35), R(0.25), R(0.15), R(0.05), R(0)};
@@ -81,6 +91,7 @@ struct Lut {
             tp->lo = tv[b]; tp->hi = tv[b1];
         }
         for (int i = tid; i < 64; i += nthreads) d[i] = tv[i >> 3] - tv[i & 7];
+      }
     }
     // byte offset (from lds0) of the entry of |x|
     __device__ __forceinline__ unsigned entry(R x) const

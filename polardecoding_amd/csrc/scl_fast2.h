@@ -21,9 +21,23 @@ namespace polar {
 template <typename R>
 struct Fast2Cfg {
     static constexpr int NLOG = 10, N = 1024, NW = 32, TOP = 9, HI = 8, L = 8;
-    static constexpr int NA = 32;   // levels 2..6, level t at offset 2^t/4
+#ifndef POLAR_F2_L6S_F64
+#define POLAR_F2_L6S_F64 0
+#endif
+#ifndef POLAR_F2_L6S_F32
+#define POLAR_F2_L6S_F32 0
+#endif
+    // L6S: level 6 stays in the scratch as well (registers hold levels 2..5): 32 fewer VGPRs in f64
+    static constexpr bool L6S = sizeof(R) == 8 ? (POLAR_F2_L6S_F64 != 0) : (POLAR_F2_L6S_F32 != 0);
+    static constexpr int NA = L6S ? 16 : 32;   // levels 2..5 (or ..6), level t at offset 2^t/4
     static constexpr int WAVES = 4;
-    static constexpr int MIN_WAVES_PER_SIMD = 3;
+#ifndef POLAR_F2_WAVES_F64
+#define POLAR_F2_WAVES_F64 3
+#endif
+#ifndef POLAR_F2_WAVES_F32
+#define POLAR_F2_WAVES_F32 4
+#endif
+    static constexpr int MIN_WAVES_PER_SIMD = sizeof(R) == 8 ? POLAR_F2_WAVES_F64 : POLAR_F2_WAVES_F32;
     static constexpr int NFA = HI - 3;  // pointer fields: LLR levels 4..8, then partial-sum levels 5..9
     // per-codeword scratch (elements of R)
     static constexpr size_t sc_l8 = 0;
@@ -95,8 +109,15 @@ struct Fast2Dec {
     __device__ __forceinline__ void f_reg()
     {
         constexpr int RO = (1 << T) / 4;
+        if constexpr (T == 5 && C::L6S) {
+            vm_drain();
+            const R *q = l6s(p) + pos;
 #pragma unroll
-        for (int r = 0; r < RO; ++r) A[RO + r] = chk(A[2 * RO + r], A[3 * RO + r]);
+            for (int r = 0; r < RO; ++r) A[RO + r] = chk(ld_sc(q + 4 * r), ld_sc(q + 4 * r + 32));
+        } else {
+#pragma unroll
+            for (int r = 0; r < RO; ++r) A[RO + r] = chk(A[2 * RO + r], A[3 * RO + r]);
+        }
         if constexpr (T >= 4) set_pa(T, p);
     }
     // ---- register levels: g from the owner's level T+1 (bpermute), T in {4, 5} ----
@@ -108,10 +129,17 @@ struct Fast2Dec {
         uint32_t w;
         if constexpr (T == 5) w = blw[pb(5) * NW + 1] >> pos;   // level 5: word 1, bit e = pos + 4r
         else w = bl0 >> (16 + pos);                              // level 4: bits 16 + e
+        if constexpr (T == 5 && C::L6S) {
+            vm_drain();
+            const R *q = l6s(pa(6)) + pos;
 #pragma unroll
-        for (int r = 0; r < RO; ++r) {
-            const R x = __shfl(A[2 * RO + r], sl), y = __shfl(A[3 * RO + r], sl);
-            A[RO + r] = g_bit<R>(x, y, w, 4 * r);
+            for (int r = 0; r < RO; ++r) A[RO + r] = g_bit<R>(ld_sc(q + 4 * r), ld_sc(q + 4 * r + 32), w, 4 * r);
+        } else {
+#pragma unroll
+            for (int r = 0; r < RO; ++r) {
+                const R x = __shfl(A[2 * RO + r], sl), y = __shfl(A[3 * RO + r], sl);
+                A[RO + r] = g_bit<R>(x, y, w, 4 * r);
+            }
         }
         set_pa(T, p);
     }
@@ -129,10 +157,12 @@ struct Fast2Dec {
     // ---- scratch levels ----
     __device__ __forceinline__ void load_l6()
     {
-        vm_drain();
-        const R *q = l6s(p) + pos;
+        if constexpr (!C::L6S) {
+            vm_drain();
+            const R *q = l6s(p) + pos;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) A[16 + r] = ld_sc(q + 4 * r);
+            for (int r = 0; r < 16; ++r) A[16 + r] = ld_sc(q + 4 * r);
+        }
         set_pa(6, p);
     }
     // d >= 8 (octets 0, 32, 64, 96): level 8 from the top level (f, or g when gstep), f down to level 6.
@@ -144,6 +174,9 @@ struct Fast2Dec {
         const uint32_t *bh = blw + pb(HI) * NW + 8;    // beta_8: words 8..15
         const R *t = tls();
         R *o8 = l8(p), *o7 = l7(p), *o6 = l6s(p);
+#ifdef POLAR_F2_UNROLL_TOP
+#pragma unroll 2
+#endif
         for (int rr = 0; rr < 16; ++rr) {
             const int e0 = pos + 4 * rr;
             const int sh = 4 * (rr & 7);
@@ -180,6 +213,9 @@ struct Fast2Dec {
         const R *s8 = l8(pa(8));
         const uint32_t *b7 = blw + pb(7) * NW + 4;  // beta_7: words 4..7
         R *o7 = l7(p), *o6 = l6s(p);
+#ifdef POLAR_F2_UNROLL_TOP
+#pragma unroll 2
+#endif
         for (int rr = 0; rr < 16; ++rr) {
             const int e0 = pos + 4 * rr;
             const int sh = 4 * (rr & 7);
@@ -200,10 +236,13 @@ struct Fast2Dec {
         const R *s7 = l7(pa(7)) + pos;
         const uint32_t *b6 = blw + pb(6) * NW + 2;  // beta_6: words 2, 3
         const uint32_t w0 = b6[0] >> pos, w1 = b6[1] >> pos;
+        R *o6 = l6s(p) + pos;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const R x = ld_sc(s7 + 4 * r), y = ld_sc(s7 + 4 * r + 64);
-            A[16 + r] = g_bit<R>(x, y, r < 8 ? w0 : w1, 4 * (r & 7));
+            const R v = g_bit<R>(x, y, r < 8 ? w0 : w1, 4 * (r & 7));
+            if constexpr (C::L6S) o6[4 * r] = v;
+            else A[16 + r] = v;
         }
         set_pa(6, p);
     }
