@@ -110,6 +110,16 @@ int polar_decode_device(polar_ctx *ctx, const void *d_in, int in_is_f32, double 
 int polar_count_errors_device(polar_ctx *ctx, const uint32_t *d_uhat_bits, const uint32_t *d_u_bits, size_t B,
                               unsigned long long *d_counters, uint32_t *d_frame_err);
 
+/* --- device-side transmit chain, throughput mode (the frame loop of main(), CASCL_1024_L8.c:245-292) -----------
+ * Fills B frames: random payload -> CRC multiply by g(D) -> u[I[i]] -> x = u F^{(x)n} -> BPSK + AWGN at
+ * Eb/N0 = snr_db (sigma = 10^(-snr_db/20), rate 1/2 as in the reference, :237) -> d_out[B][N] (double, or float
+ * when out_is_f32; channel LLRs 2y/sigma/sigma, or y when out_is_y) and d_u_bits[B][N/32] (nullable).
+ * Counter-based generator: frame (first_frame + f) depends only on (seed, frame index), so batches can be cut
+ * and sharded over GPUs freely.  This is NOT the reference's sequential Ranq1 stream (that one stays on the
+ * host: polar_sim.c); use it for throughput / FER runs, not for reproducing published run counts. */
+int polar_generate_device(polar_ctx *ctx, unsigned long long seed, unsigned long long first_frame, double snr_db,
+                          size_t B, void *d_out, int out_is_f32, int out_is_y, uint32_t *d_u_bits);
+
 /* stream plumbing: the ctx owns a stream by default; a host framework may hand in its own
  * (hipStream_t passed as void*). */
 int polar_set_stream(polar_ctx *ctx, void *hip_stream);

@@ -69,6 +69,8 @@ def load_library():
     L.polar_decode_batch_y.argtypes = [vp, dp, C.c_double, C.c_size_t, ip, dp, up]
     L.polar_decode_device.argtypes = [vp, vp, C.c_int, C.c_double, C.c_size_t, vp, vp, vp]
     L.polar_count_errors_device.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
+    L.polar_generate_device.argtypes = [vp, C.c_ulonglong, C.c_ulonglong, C.c_double, C.c_size_t, vp, C.c_int,
+                                        C.c_int, vp]
     L.polar_set_stream.argtypes = [vp, vp]
     L.polar_get_stream.restype = vp
     L.polar_get_stream.argtypes = [vp]
@@ -213,6 +215,17 @@ class Decoder:
             C.c_void_p(pm.data_ptr()) if pm is not None else None,
             C.c_void_p(flags.data_ptr()) if flags is not None else None), "polar_decode_device")
         return out_bits
+
+    def generate_device(self, seed, first_frame, snr_db, out, u_bits=None, out_is_y=False):
+        """Device-side transmit chain (throughput mode): fills `out` [B][N] (float64/float32 LLRs, or y) and
+        `u_bits` [B][N/32] int32 for frames first_frame .. first_frame + B - 1 of stream `seed`."""
+        import torch
+        B = out.numel() // self.N
+        self._check(self._lib.polar_generate_device(
+            self._h, int(seed), int(first_frame), float(snr_db), B, C.c_void_p(out.data_ptr()),
+            1 if out.dtype == torch.float32 else 0, 1 if out_is_y else 0,
+            C.c_void_p(u_bits.data_ptr()) if u_bits is not None else None), "polar_generate_device")
+        return out
 
     def count_errors_device(self, uhat_bits, u_bits, counters, frame_err=None):
         B = uhat_bits.shape[0]

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "bp_kernel.h"
+#include "gen_kernel.h"
 #include "scl_fast.h"
 #include "scl_fast2.h"
 #include "scl_generic.h"
@@ -42,6 +43,7 @@ struct polar_ctx {
     uint32_t *d_info = nullptr;           // [NW] bit = unfrozen
     uint32_t *d_crc_tab = nullptr;        // [N] or null
     uint32_t *d_frozen_override = nullptr;
+    int *d_info_order = nullptr;          // [A] for the device-side generator
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 0;
@@ -497,6 +499,7 @@ void polar_destroy(polar_ctx *c)
     if (c->d_info) (void)hipFree(c->d_info);
     if (c->d_crc_tab) (void)hipFree(c->d_crc_tab);
     if (c->d_frozen_override) (void)hipFree(c->d_frozen_override);
+    if (c->d_info_order) (void)hipFree(c->d_info_order);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -615,6 +618,37 @@ int polar_count_errors_device(polar_ctx *c, const uint32_t *d_uhat, const uint32
     const int waves_per_block = 4;
     int grid = (int)std::min<size_t>((B + waves_per_block - 1) / waves_per_block, (size_t)c->num_cu * 8);
     hipLaunchKernelGGL(polar::k_count_errors, dim3(grid), dim3(64 * waves_per_block), 0, c->stream, P);
+    HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
+int polar_generate_device(polar_ctx *c, unsigned long long seed, unsigned long long first_frame, double snr_db,
+                          size_t B, void *d_out, int out_is_f32, int out_is_y, uint32_t *d_u_bits)
+{
+    if (!c || !d_out || B > 0x7fffffffull) return POLAR_EINVAL;
+    if (B == 0) return POLAR_OK;
+    const polar_cfg &g = c->cfg;
+    if (g.N < 64) return POLAR_EINVAL;
+    if (!c->d_info_order) {
+        HIP_TRY(c, hipMalloc(&c->d_info_order, sizeof(int) * (size_t)c->A));
+        HIP_TRY(c, hipMemcpy(c->d_info_order, c->info_order.data(), sizeof(int) * (size_t)c->A, hipMemcpyHostToDevice));
+    }
+    polar::GenParams P{};
+    P.out = d_out; P.u_bits = d_u_bits; P.info_order = c->d_info_order;
+    P.seed = seed; P.first_frame = first_frame;
+    P.sigma = std::pow(10.0, snr_db / -20.0);  // SCL_1024.c:226
+    P.crc_r = g.crc_r; P.crc_mask = 0; P.crc_top = 0;
+    if (g.crc_r == 0) P.crc_mask = 1u;
+    for (int t : c->taps) {
+        if (t < 32) P.crc_mask |= 1u << t;
+        else P.crc_top = 1u;
+    }
+    P.N = g.N; P.n = c->n; P.K = g.K; P.A = c->A; P.B = (int)B;
+    P.out_is_f32 = out_is_f32; P.out_is_y = out_is_y;
+    const int waves = 4;
+    const size_t lds = (size_t)waves * (g.N + 2 * 1024);
+    int grid = (int)std::min<size_t>((B + waves - 1) / waves, (size_t)c->num_cu * 8);
+    hipLaunchKernelGGL(polar::k_generate, dim3(grid), dim3(64 * waves), lds, c->stream, P);
     HIP_TRY(c, hipGetLastError());
     return POLAR_OK;
 }

@@ -1,0 +1,112 @@
+"""GPU: device-side transmit chain (polar_generate_device) -- encoder, CRC, noise statistics,
+sharding invariance, and FER through generator + decoder against the reference's published BLER."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _unpack(words, N):
+    w = words.cpu().numpy().view(np.uint32).reshape(-1, N // 32)
+    return ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1, N).astype(np.uint8)
+
+
+def _polar(u):
+    x = u.copy()
+    s = 1
+    N = x.shape[1]
+    while s < N:
+        v = x.reshape(x.shape[0], N // (2 * s), 2, s)
+        v[:, :, 0, :] ^= v[:, :, 1, :]
+        s *= 2
+    return x
+
+
+@pytest.mark.parametrize("N,K,taps", [(1024, 512, (0, 1, 2, 4, 8, 12, 13, 15, 17, 20, 21, 23, 24)), (128, 64, (0, 5, 6)),
+                                      (1024, 512, None)])
+def test_generator_encoder_and_crc(N, K, taps):
+    import torch
+    import polardecoding_amd as pa
+    dec = pa.CASCL(N, K, L=8, crc_taps=taps) if taps else pa.SCLdecode(N, K, L=8)
+    B = 256
+    y = torch.empty(B, N, dtype=torch.float64, device="cuda")
+    ub = torch.empty(B, N // 32, dtype=torch.int32, device="cuda")
+    dec.generate_device(7, 0, 40.0, y, ub, out_is_y=True)   # 40 dB: y = +-1 + 1e-2 noise
+    dec.synchronize()
+    u = _unpack(ub, N)
+    io = dec.info_order
+    frozen = np.ones(N, bool)
+    frozen[io] = False
+    assert not u[:, frozen].any()
+    assert 0.4 < u[:, io].mean() < 0.6
+    x = _polar(u)
+    hard = (y.cpu().numpy() < 0).astype(np.uint8)
+    assert np.array_equal(hard, x)                            # BPSK of x = u F^{(x)n}
+    if taps:                                                   # every frame is a multiple of g(D)
+        r = max(taps)
+        rem = u[:, io].copy()
+        for i in range(rem.shape[1] - 1, r - 1, -1):
+            rows = rem[:, i] == 1
+            for t in taps:
+                rem[rows, i - r + t] ^= 1
+        assert not rem[:, :r].any()
+
+
+def test_generator_depends_only_on_seed_and_frame_index():
+    import torch
+    import polardecoding_amd as pa
+    dec = pa.CASCL(1024, 512, L=8)
+    a = torch.empty(64, 1024, dtype=torch.float64, device="cuda")
+    b0 = torch.empty(24, 1024, dtype=torch.float64, device="cuda")
+    b1 = torch.empty(40, 1024, dtype=torch.float64, device="cuda")
+    ua = torch.empty(64, 32, dtype=torch.int32, device="cuda")
+    dec.generate_device(99, 1000, 2.0, a, ua)
+    dec.generate_device(99, 1000, 2.0, b0)
+    dec.generate_device(99, 1024, 2.0, b1)
+    dec.synchronize()
+    assert torch.equal(a[:24], b0) and torch.equal(a[24:], b1)
+    c = torch.empty(64, 1024, dtype=torch.float64, device="cuda")
+    dec.generate_device(100, 1000, 2.0, c)
+    dec.synchronize()
+    assert not torch.equal(a, c)
+
+
+def test_generator_noise_statistics():
+    import torch
+    import polardecoding_amd as pa
+    dec = pa.CASCL(1024, 512, L=8)
+    B = 1 << 13
+    y = torch.empty(B, 1024, dtype=torch.float64, device="cuda")
+    ub = torch.empty(B, 32, dtype=torch.int32, device="cuda")
+    dec.generate_device(3, 0, 0.0, y, ub, out_is_y=True)      # sigma = 1
+    dec.synchronize()
+    x = torch.from_numpy(_polar(_unpack(ub, 1024))).cuda().double()
+    nz = y - (1 - 2 * x)
+    n = nz.numel()
+    assert abs(nz.mean().item()) < 5 / math.sqrt(n)
+    assert abs(nz.var().item() - 1) < 5 * math.sqrt(2 / n)
+    assert abs((nz ** 4).mean().item() - 3) < 0.05
+    # no correlation between neighbouring samples (the two Box-Muller outputs, neighbouring lanes)
+    assert abs((nz[:, :-1] * nz[:, 1:]).mean().item()) < 5 / math.sqrt(n)
+    assert abs((nz[:, :-64] * nz[:, 64:]).mean().item()) < 5 / math.sqrt(n)
+
+
+def test_fer_with_device_generator_matches_published():
+    """CA-SCL N=1024 L=8 at 1.5 dB: published BLER 0.0724 (CASCL_L8.dat, 100 errors)."""
+    import torch
+    import polardecoding_amd as pa
+    dec = pa.CASCL(1024, 512, L=8)
+    B = 1 << 15
+    llr = torch.empty(B, 1024, dtype=torch.float64, device="cuda")
+    ub = torch.empty(B, 32, dtype=torch.int32, device="cuda")
+    dec.generate_device(2026, 0, 1.5, llr, ub)
+    bits = dec.decode_device(llr)
+    c = torch.zeros(2, dtype=torch.int64, device="cuda")
+    dec.count_errors_device(bits, ub, c)
+    dec.synchronize()
+    fer = int(c[0]) / B
+    ref = 0.072411
+    sig = math.sqrt(ref * (1 - ref) / B + ref * ref / 100)
+    assert abs(fer - ref) < 4 * sig, fer
