@@ -120,6 +120,12 @@ int polar_count_errors_device(polar_ctx *ctx, const uint32_t *d_uhat_bits, const
 int polar_generate_device(polar_ctx *ctx, unsigned long long seed, unsigned long long first_frame, double snr_db,
                           size_t B, void *d_out, int out_is_f32, int out_is_y, uint32_t *d_u_bits);
 
+/* One throughput-mode Monte-Carlo batch entirely on the device: generate (as polar_generate_device) -> decode ->
+ * count (main()'s loop body, CASCL_1024_L8.c:245-305, B times).  Adds the batch's block and bit errors to
+ * *block_errors / *bit_errors (host counters).  Buffers are owned and reused by the ctx. */
+int polar_fer_batch(polar_ctx *ctx, unsigned long long seed, unsigned long long first_frame, double snr_db, size_t B,
+                    unsigned long long *block_errors, unsigned long long *bit_errors);
+
 /* stream plumbing: the ctx owns a stream by default; a host framework may hand in its own
  * (hipStream_t passed as void*). */
 int polar_set_stream(polar_ctx *ctx, void *hip_stream);

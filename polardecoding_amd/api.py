@@ -71,6 +71,8 @@ def load_library():
     L.polar_count_errors_device.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
     L.polar_generate_device.argtypes = [vp, C.c_ulonglong, C.c_ulonglong, C.c_double, C.c_size_t, vp, C.c_int,
                                         C.c_int, vp]
+    L.polar_fer_batch.argtypes = [vp, C.c_ulonglong, C.c_ulonglong, C.c_double, C.c_size_t, C.POINTER(C.c_ulonglong),
+                                  C.POINTER(C.c_ulonglong)]
     L.polar_set_stream.argtypes = [vp, vp]
     L.polar_get_stream.restype = vp
     L.polar_get_stream.argtypes = [vp]
@@ -226,6 +228,13 @@ class Decoder:
             1 if out.dtype == torch.float32 else 0, 1 if out_is_y else 0,
             C.c_void_p(u_bits.data_ptr()) if u_bits is not None else None), "polar_generate_device")
         return out
+
+    def fer_batch(self, seed, first_frame, snr_db, B):
+        """generate -> decode -> count for B frames on the device; returns (block_errors, bit_errors)."""
+        blk, bits = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._check(self._lib.polar_fer_batch(self._h, int(seed), int(first_frame), float(snr_db), int(B),
+                                              C.byref(blk), C.byref(bits)), "polar_fer_batch")
+        return blk.value, bits.value
 
     def count_errors_device(self, uhat_bits, u_bits, counters, frame_err=None):
         B = uhat_bits.shape[0]

@@ -49,6 +49,7 @@ struct polar_ctx {
     int num_cu = 0;
     Buf in, bits, pm, flags;              // staging for the host-pointer entry points
     Buf scratch;                          // k_scl_fast per-wave scratch
+    Buf gen_llr, gen_u, gen_cnt;          // polar_fer_batch
     std::string last_error;
     std::string kernel_name;
     bool force_generic = false;
@@ -493,7 +494,7 @@ void polar_destroy(polar_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (Buf *b : {&c->in, &c->bits, &c->pm, &c->flags, &c->scratch})
+    for (Buf *b : {&c->in, &c->bits, &c->pm, &c->flags, &c->scratch, &c->gen_llr, &c->gen_u, &c->gen_cnt})
         if (b->p) (void)hipFree(b->p);
     if (c->d_frozen) (void)hipFree(c->d_frozen);
     if (c->d_info) (void)hipFree(c->d_info);
@@ -650,6 +651,34 @@ int polar_generate_device(polar_ctx *c, unsigned long long seed, unsigned long l
     int grid = (int)std::min<size_t>((B + waves - 1) / waves, (size_t)c->num_cu * 8);
     hipLaunchKernelGGL(polar::k_generate, dim3(grid), dim3(64 * waves), lds, c->stream, P);
     HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
+int polar_fer_batch(polar_ctx *c, unsigned long long seed, unsigned long long first_frame, double snr_db, size_t B,
+                    unsigned long long *block_errors, unsigned long long *bit_errors)
+{
+    if (!c || !block_errors || !bit_errors) return POLAR_EINVAL;
+    if (B == 0) return POLAR_OK;
+    const int N = c->cfg.N, NW = c->NW;
+    const bool f32 = c->cfg.dtype == POLAR_F32;
+    int rc;
+    if ((rc = ensure(c, c->gen_llr, B * N * (f32 ? 4 : 8)))) return rc;
+    if ((rc = ensure(c, c->gen_u, B * NW * 4))) return rc;
+    if ((rc = ensure(c, c->bits, B * NW * 4))) return rc;
+    if ((rc = ensure(c, c->gen_cnt, 16))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->gen_cnt.p, 0, 16, c->stream));
+    if ((rc = polar_generate_device(c, seed, first_frame, snr_db, B, c->gen_llr.p, f32 ? 1 : 0, 0, (uint32_t *)c->gen_u.p)))
+        return rc;
+    if ((rc = decode_device_impl(c, c->gen_llr.p, f32 ? 1 : 0, 0.0, B, (uint32_t *)c->bits.p, nullptr, nullptr, c->d_frozen)))
+        return rc;
+    if ((rc = polar_count_errors_device(c, (uint32_t *)c->bits.p, (uint32_t *)c->gen_u.p, B,
+                                        (unsigned long long *)c->gen_cnt.p, nullptr)))
+        return rc;
+    unsigned long long h[2];
+    HIP_TRY(c, hipMemcpyAsync(h, c->gen_cnt.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *block_errors += h[0];
+    *bit_errors += h[1];
     return POLAR_OK;
 }
 
