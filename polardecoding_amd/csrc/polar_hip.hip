@@ -305,11 +305,11 @@ int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sig
         atexit([] {
             unsigned long long h[8];
             (void)hipMemcpy(h, s_dbg, sizeof h, hipMemcpyDeviceToHost);
-            const char *nm[8] = {"prologue", "load ch", "tl+init", "octet_head", "octet frozen-prefix", "octet generic",
-                                 "select+store", "-"};
+            const char *nm[8] = {"prologue", "load ch", "tl+init", "octet_head (d<6)", "octet frozen-prefix", "octet generic",
+                                 "select+store", "octet_head (d>=6, scratch levels)"};
             unsigned long long tot = 0;
             for (int i = 0; i < 8; ++i) tot += h[i];
-            for (int i = 0; i < 7; ++i)
+            for (int i = 0; i < 8; ++i)
                 fprintf(stderr, "[stamps] %-22s %14llu ticks  %5.1f %%\n", nm[i], h[i], 100.0 * h[i] / (tot ? tot : 1));
         });
     }

@@ -136,6 +136,17 @@ __device__ __forceinline__ float xor_sign(float m, float a, float b)
     return __int_as_float((int)((x & 0x80000000u) | (unsigned)__float_as_int(m)));
 }
 
+// One-round-trip form: T(|s|) and T(|d|) are selected from the cell entries and subtracted here (the reference's
+// own `delta = T(s); delta -= T(d)`), instead of a second, dependent read of the 8x8 difference table.
+// Four more issue slots, one LDS latency less: for the serial narrow-level chains.
+template <typename R>
+__device__ __forceinline__ R chk_lut1(R a, R b, const Lut<R> &L)
+{
+    const R s = a + b, d = a - b;
+    const R delta = L.tabv(s) - L.tabv(d);
+    return xor_sign(minabs(a, b), a, b) + delta;
+}
+
 // CHK (SCL_1024.c:343-374) with the staircase taken from the tables.  sign(a)sign(b) is applied by
 // xor of the sign bits: for a = -0.0 the reference uses +1, but then min = 0 and delta = +0, and
 // (+-0) + (+0) = +0 either way, so the result is identical.

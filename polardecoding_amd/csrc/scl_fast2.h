@@ -57,7 +57,8 @@ struct Fast2Cfg {
     static constexpr size_t off_cw = off_bl + 4 * 2 * 8 * NW;  // working partial sums [2][8][NW]
     static constexpr size_t off_cd = off_cw + 4 * 2 * 8 * NW;  // candidates [2][16]
     static constexpr size_t off_ky = off_cd + sizeof(R) * 32;  // keys [2][16]
-    static constexpr size_t per_wave = off_ky + 128;
+    static constexpr size_t off_sg = off_ky + 128;             // top-level staging [2][256]
+    static constexpr size_t per_wave = off_sg + sizeof(R) * 512;
     static constexpr size_t total = shared_bytes + WAVES * per_wave;
 };
 
@@ -80,7 +81,7 @@ struct Fast2Dec {
     int own_addr, oth_addr;    // rank network: byte addresses into keys[]
     int cand_addr;
     Lut<R> lut;
-    R *cand;
+    R *cand, *stg;
     uint32_t *blw, *curw, *keys;   // this lane's codeword slice of the per-wave arrays
     const uint32_t *crct;
     const unsigned char *kth;
@@ -93,16 +94,28 @@ struct Fast2Dec {
     __device__ __forceinline__ int pb(int t) const { return (ptr >> (3 * (NFA + t - 5))) & 7; }
     __device__ __forceinline__ void set_pb(int t, int v) { ptr = (ptr & ~(7u << (3 * (NFA + t - 5)))) | ((uint32_t)v << (3 * (NFA + t - 5))); }
     __device__ __forceinline__ R chk(R a, R b) const { return chk_lut<R>(a, b, lut); }
+#ifdef POLAR_F2_CHK1
+    __device__ __forceinline__ R chks(R a, R b) const { return chk_lut1<R>(a, b, lut); }  // serial chains
+#else
+    __device__ __forceinline__ R chks(R a, R b) const { return chk_lut<R>(a, b, lut); }
+#endif
     __device__ __forceinline__ R chv(int e) const
     {
         double v = (double)src[e];
         if (sigma > 0) v = llr_from_y(v, sigma);
         return (R)v;
     }
-    __device__ __forceinline__ R *l8(int slot) const { return scr + C::sc_l8 + slot * 256; }
-    __device__ __forceinline__ R *l7(int slot) const { return scr + C::sc_l7 + slot * 128; }
-    __device__ __forceinline__ R *l6s(int slot) const { return scr + C::sc_l6 + slot * 64; }
-    __device__ __forceinline__ R *tls() const { return scr + C::sc_tl; }
+    // The row addresses are recomputed where they are used (a few instructions, 16 times per frame) instead of
+    // being hoisted out of the frame loop into long-lived 64-bit registers: the empty asm stops the hoisting.
+    static __device__ __forceinline__ unsigned fresh(unsigned off)
+    {
+        __asm__ volatile("" : "+v"(off));
+        return off;
+    }
+    __device__ __forceinline__ R *l8(int slot) const { return scr + fresh(C::sc_l8 + slot * 256); }
+    __device__ __forceinline__ R *l7(int slot) const { return scr + fresh(C::sc_l7 + slot * 128); }
+    __device__ __forceinline__ R *l6s(int slot) const { return scr + fresh(C::sc_l6 + slot * 64); }
+    __device__ __forceinline__ R *tls() const { return scr + fresh(C::sc_tl); }
 
     // ---- register levels: f on own data ----
     template <int T>  // T in [2, 5]: level T from level T+1
@@ -167,65 +180,101 @@ struct Fast2Dec {
     }
     // d >= 8 (octets 0, 32, 64, 96): level 8 from the top level (f, or g when gstep), f down to level 6.
     // Pass rr: level-8 elements e0 + 64k (k < 4), level-7 elements e0, e0 + 64, level-6 element e0 = pos + 4 rr.
+    // The top-level operands are the same for all eight paths of a codeword, so the codeword's 32 lanes fetch
+    // them once per chunk of 4 passes (16 segments of 16 consecutive elements), park them in an LDS staging
+    // buffer and every path reads them from there; the next chunk's loads are in flight during the compute.
+    __device__ __forceinline__ R top_src(bool right, int idx, int q) const
+    {
+        // staging index idx = seg*16 + within; seg = k + 4*h: right: h selects ch offset {0,256,512,768};
+        // left: h in {0,1} selects tl offset {0,256}
+        const int seg = idx >> 4, within = idx & 15;
+        const int e = 16 * q + within + 64 * (seg & 3) + 256 * (seg >> 2);
+        return right ? chv(e) : ld_sc(tls() + e);
+    }
     __device__ __forceinline__ void from_top(bool right, bool gstep)
     {
         vm_drain();
         const uint32_t *bt = blw + pb(TOP) * NW + 16;  // beta_9: words 16..31
         const uint32_t *bh = blw + pb(HI) * NW + 8;    // beta_8: words 8..15
-        const R *t = tls();
         R *o8 = l8(p), *o7 = l7(p), *o6 = l6s(p);
-#ifdef POLAR_F2_UNROLL_TOP
-#pragma unroll 2
-#endif
-        for (int rr = 0; rr < 16; ++rr) {
-            const int e0 = pos + 4 * rr;
-            const int sh = 4 * (rr & 7);
-            const int wq = rr >> 3;
-            R v8[4];
+        const int w32 = p * 4 + pos;                   // lane index inside the codeword
+        const int nld = right ? 8 : 4;                 // staged elements per lane and chunk
+        R *pre = A + 16;   // levels 2..6 are dead during this step (recomputed below): reuse their registers
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = e0 + 64 * k;
-                R x, y;
-                if (right) {
-                    const uint32_t w0 = bt[2 * k + wq] >> pos, w1 = bt[8 + 2 * k + wq] >> pos;
-                    x = g_bit<R>(chv(e), chv(e + 512), w0, sh);
-                    y = g_bit<R>(chv(e + 256), chv(e + 768), w1, sh);
-                } else {
-                    x = ld_sc(t + e);
-                    y = ld_sc(t + e + 256);
-                }
-                if (gstep) v8[k] = g_bit<R>(x, y, bh[2 * k + wq] >> pos, sh);
-                else v8[k] = chk(x, y);
-                o8[e] = v8[k];
+        for (int m = 0; m < 8; ++m) pre[m] = (m < nld) ? top_src(right, w32 + 32 * m, 0) : R(0);
+        for (int q = 0; q < 4; ++q) {
+            lds_fence();
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                if (m < nld) stg[w32 + 32 * m] = pre[m];
+            lds_fence();
+            if (q < 3) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) pre[m] = (m < nld) ? top_src(right, w32 + 32 * m, q + 1) : R(0);
             }
-            const R v70 = chk(v8[0], v8[2]), v71 = chk(v8[1], v8[3]);
-            o7[e0] = v70;
-            o7[e0 + 64] = v71;
-            o6[e0] = chk(v70, v71);
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                const int rr = 4 * q + i;
+                const int e0 = pos + 4 * rr;
+                const int sh = 4 * (rr & 7);
+                const int wq = rr >> 3;
+                const int wi = 4 * i + pos;  // position inside a staged segment
+                R *v8 = A + 8;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = e0 + 64 * k;
+                    R x, y;
+                    if (right) {
+                        const uint32_t w0 = bt[2 * k + wq] >> pos, w1 = bt[8 + 2 * k + wq] >> pos;
+                        x = g_bit<R>(stg[(k + 0) * 16 + wi], stg[(k + 8) * 16 + wi], w0, sh);    // ch[e], ch[e+512]
+                        y = g_bit<R>(stg[(k + 4) * 16 + wi], stg[(k + 12) * 16 + wi], w1, sh);   // ch[e+256], ch[e+768]
+                    } else {
+                        x = stg[(k + 0) * 16 + wi];   // tl[e]
+                        y = stg[(k + 4) * 16 + wi];   // tl[e+256]
+                    }
+                    if (gstep) v8[k] = g_bit<R>(x, y, bh[2 * k + wq] >> pos, sh);
+                    else v8[k] = chk(x, y);
+                    o8[e] = v8[k];
+                }
+                const R v70 = chk(v8[0], v8[2]), v71 = chk(v8[1], v8[3]);
+                o7[e0] = v70;
+                o7[e0 + 64] = v71;
+                o6[e0] = chk(v70, v71);
+            }
         }
         set_pa(8, p);
         set_pa(7, p);
         load_l6();
     }
-    __device__ __forceinline__ void from_l8()  // d == 7
+    // d == 7: g to level 7 from the owner's level 8, f to level 6.  Four passes per chunk: their 16 loads go out
+    // together into the (dead at this point) level-6 registers.
+    __device__ __forceinline__ void from_l8()
     {
         vm_drain();
         const R *s8 = l8(pa(8));
         const uint32_t *b7 = blw + pb(7) * NW + 4;  // beta_7: words 4..7
         R *o7 = l7(p), *o6 = l6s(p);
-#ifdef POLAR_F2_UNROLL_TOP
-#pragma unroll 2
-#endif
-        for (int rr = 0; rr < 16; ++rr) {
-            const int e0 = pos + 4 * rr;
-            const int sh = 4 * (rr & 7);
-            const int wq = rr >> 3;
-            const R x0 = ld_sc(s8 + e0), x1 = ld_sc(s8 + e0 + 64), x2 = ld_sc(s8 + e0 + 128), x3 = ld_sc(s8 + e0 + 192);
-            const R v70 = g_bit<R>(x0, x2, b7[wq] >> pos, sh);
-            const R v71 = g_bit<R>(x1, x3, b7[2 + wq] >> pos, sh);
-            o7[e0] = v70;
-            o7[e0 + 64] = v71;
-            o6[e0] = chk(v70, v71);
+        constexpr int CP = sizeof(R) == 8 ? 2 : 4;   // passes per chunk (loads in flight: 4 per pass)
+        for (int q = 0; q < 16 / CP; ++q) {
+            R *in = A + 16;  // level-6 registers: dead here, rewritten by load_l6()
+#pragma unroll
+            for (int i = 0; i < CP; ++i) {
+                const int e0 = pos + 4 * (CP * q + i);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) in[4 * i + k] = ld_sc(s8 + e0 + 64 * k);
+            }
+#pragma unroll
+            for (int i = 0; i < CP; ++i) {
+                const int rr = CP * q + i;
+                const int e0 = pos + 4 * rr;
+                const int sh = 4 * (rr & 7);
+                const int wq = rr >> 3;
+                const R v70 = g_bit<R>(in[4 * i], in[4 * i + 2], b7[wq] >> pos, sh);
+                const R v71 = g_bit<R>(in[4 * i + 1], in[4 * i + 3], b7[2 + wq] >> pos, sh);
+                o7[e0] = v70;
+                o7[e0 + 64] = v71;
+                o6[e0] = chk(v70, v71);
+            }
         }
         set_pa(7, p);
         load_l6();
@@ -426,11 +475,11 @@ struct Fast2Dec {
     __device__ __forceinline__ void octet_frozen_prefix(int o, bool last_frozen)
     {
         // level 2: f half (leaves 0..3) and g half (leaves 4..7), element pos each
-        R xf = chk(A[2], A[3]), xg = A[3] + A[2];
+        R xf = chks(A[2], A[3]), xg = A[3] + A[2];
         // level 1: lanes pos 0,1 = f results, lanes 2,3 = g results, for both halves
         R yf = quadp<0x4E>(xf), yg = quadp<0x4E>(xg);  // lane ^ 2
         {
-            const R ff = chk(xf, yf), gf = xf + yf, fg = chk(xg, yg), gg = xg + yg;
+            const R ff = chks(xf, yf), gf = xf + yf, fg = chks(xg, yg), gg = xg + yg;
             xf = (pos & 2) ? gf : ff;
             xg = (pos & 2) ? gg : fg;
         }
@@ -438,7 +487,7 @@ struct Fast2Dec {
         yf = quadp<0xB1>(xf); yg = quadp<0xB1>(xg);    // lane ^ 1
         R lf, lg;
         {
-            const R ff = chk(xf, yf), gf = xf + yf, fg = chk(xg, yg), gg = xg + yg;
+            const R ff = chks(xf, yf), gf = xf + yf, fg = chks(xg, yg), gg = xg + yg;
             lf = (pos & 1) ? gf : ff;
             lg = (pos & 1) ? gg : fg;
         }
@@ -463,25 +512,25 @@ struct Fast2Dec {
     __device__ __forceinline__ void octet(int o, uint32_t fm)
     {
         // leaf 0: f2 f1 f0
-        A[1] = chk(A[2], A[3]);
-        a1 = chk(A[1], quadp<0x4E>(A[1]));
-        decide<0>(o, fm & 1, chk(a1, quadp<0xB1>(a1)));
+        A[1] = chks(A[2], A[3]);
+        a1 = chks(A[1], quadp<0x4E>(A[1]));
+        decide<0>(o, fm & 1, chks(a1, quadp<0xB1>(a1)));
         // leaf 1: g0
         decide<1>(o, (fm >> 1) & 1, g_bit<R>(a1, quadp<0xB1>(a1), bl0, 1));
         // leaf 2: g1 f0
         a1 = g_bit<R>(A[1], quadp<0x4E>(A[1]), bl0, 2 + pos);
-        decide<2>(o, (fm >> 2) & 1, chk(a1, quadp<0xB1>(a1)));
+        decide<2>(o, (fm >> 2) & 1, chks(a1, quadp<0xB1>(a1)));
         // leaf 3: g0
         decide<3>(o, (fm >> 3) & 1, g_bit<R>(a1, quadp<0xB1>(a1), bl0, 1));
         // leaf 4: g2 f1 f0
         A[1] = g_bit<R>(A[2], A[3], bl0, 4 + pos);
-        a1 = chk(A[1], quadp<0x4E>(A[1]));
-        decide<4>(o, (fm >> 4) & 1, chk(a1, quadp<0xB1>(a1)));
+        a1 = chks(A[1], quadp<0x4E>(A[1]));
+        decide<4>(o, (fm >> 4) & 1, chks(a1, quadp<0xB1>(a1)));
         // leaf 5: g0
         decide<5>(o, (fm >> 5) & 1, g_bit<R>(a1, quadp<0xB1>(a1), bl0, 1));
         // leaf 6: g1 f0
         a1 = g_bit<R>(A[1], quadp<0x4E>(A[1]), bl0, 2 + pos);
-        decide<6>(o, (fm >> 6) & 1, chk(a1, quadp<0xB1>(a1)));
+        decide<6>(o, (fm >> 6) & 1, chks(a1, quadp<0xB1>(a1)));
         // leaf 7: g0
         decide<7>(o, (fm >> 7) & 1, g_bit<R>(a1, quadp<0xB1>(a1), bl0, 1));
     }
@@ -490,6 +539,10 @@ struct Fast2Dec {
 template <typename R, typename IN, bool CRC_ON>
 __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_fast2(SclParams P)
 {
+#ifdef POLAR_STAMPS
+    unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
     using D = Fast2Dec<R, IN, CRC_ON>;
     using C = Fast2Cfg<R>;
     constexpr int N = C::N, NW = C::NW, L = 8;
@@ -528,6 +581,7 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
     s.curw = reinterpret_cast<uint32_t *>(base + C::off_cw) + s.c * 8 * NW;
     s.cand = reinterpret_cast<R *>(base + C::off_cd) + s.c * 16;
     s.keys = reinterpret_cast<uint32_t *>(base + C::off_ky) + s.c * 16;
+    s.stg = reinterpret_cast<R *>(base + C::off_sg) + s.c * 256;
     s.sigma = P.sigma;
     {   // rank network: lane (row, i): rows 0,1 -> codeword 0, rows 2,3 -> codeword 1; candidate i is
         // (slot i & 7, branch i >> 3) stored at keys[cw][2*slot + branch]
@@ -570,12 +624,14 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
         s.logact = 0;
         uint32_t fword = 0;
 
+        STAMP(2);
         for (int o = 0; o < N / 8; ++o) {
             if ((o & 3) == 0) fword = frz[o >> 2];
             s.octet_head(o);
+            if (o == 0 || (o & 7) == 0) STAMP(7); else STAMP(3);
             const uint32_t fm = (fword >> (8 * (o & 3))) & 0xFFu;
-            if ((fm & 0x7Fu) == 0x7Fu) s.octet_frozen_prefix(o, fm == 0xFFu);
-            else s.octet(o, fm);
+            if ((fm & 0x7Fu) == 0x7Fu) { s.octet_frozen_prefix(o, fm == 0xFFu); STAMP(4); }
+            else { s.octet(o, fm); STAMP(5); }
         }
 
         // ---- choose the path, per codeword (SCL_1024.c:667-674; CASCL_1024_L8.c:725-755) ----
@@ -619,7 +675,12 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
             if (P.flags) P.flags[frame] = fl;
         }
         lds_fence();
+        STAMP(6);
     }
+#ifdef POLAR_STAMPS
+    if (P.dbg && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&P.dbg[i], tsec[i]);
+#endif
 }
 
 }  // namespace polar
