@@ -168,16 +168,20 @@ struct Fast2Dec {
     }
 
     // ---- scratch levels ----
-    __device__ __forceinline__ void load_l6()
+    // The level-6 value of pass rr (element pos + 4 rr).  Registers: the 16 level-6 registers act as a shift
+    // register -- after the 16 passes of a step the value of pass rr sits in A[16 + rr] -- so the pass loops can
+    // stay rolled without a dynamically indexed register and without a round trip through memory.
+    __device__ __forceinline__ void push_l6(R v, R *o6, int e0)
     {
-        if constexpr (!C::L6S) {
-            vm_drain();
-            const R *q = l6s(p) + pos;
+        if constexpr (C::L6S) {
+            o6[e0] = v;
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) A[16 + r] = ld_sc(q + 4 * r);
+            for (int r = 16; r < 31; ++r) A[r] = A[r + 1];
+            A[31] = v;
         }
-        set_pa(6, p);
     }
+    __device__ __forceinline__ void load_l6() { set_pa(6, p); }
     // d >= 8 (octets 0, 32, 64, 96): level 8 from the top level (f, or g when gstep), f down to level 6.
     // Pass rr: level-8 elements e0 + 64k (k < 4), level-7 elements e0, e0 + 64, level-6 element e0 = pos + 4 rr.
     // The top-level operands are the same for all eight paths of a codeword, so the codeword's 32 lanes fetch
@@ -199,7 +203,7 @@ struct Fast2Dec {
         R *o8 = l8(p), *o7 = l7(p), *o6 = l6s(p);
         const int w32 = p * 4 + pos;                   // lane index inside the codeword
         const int nld = right ? 8 : 4;                 // staged elements per lane and chunk
-        R *pre = A + 16;   // levels 2..6 are dead during this step (recomputed below): reuse their registers
+        R *pre = A + 4;    // levels 2..5 are dead during this step (recomputed below): reuse their registers
 #pragma unroll
         for (int m = 0; m < 8; ++m) pre[m] = (m < nld) ? top_src(right, w32 + 32 * m, 0) : R(0);
         for (int q = 0; q < 4; ++q) {
@@ -219,7 +223,7 @@ struct Fast2Dec {
                 const int sh = 4 * (rr & 7);
                 const int wq = rr >> 3;
                 const int wi = 4 * i + pos;  // position inside a staged segment
-                R *v8 = A + 8;
+                R *v8 = A + 12;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int e = e0 + 64 * k;
@@ -239,7 +243,7 @@ struct Fast2Dec {
                 const R v70 = chk(v8[0], v8[2]), v71 = chk(v8[1], v8[3]);
                 o7[e0] = v70;
                 o7[e0 + 64] = v71;
-                o6[e0] = chk(v70, v71);
+                push_l6(chk(v70, v71), o6, e0);
             }
         }
         set_pa(8, p);
@@ -254,9 +258,9 @@ struct Fast2Dec {
         const R *s8 = l8(pa(8));
         const uint32_t *b7 = blw + pb(7) * NW + 4;  // beta_7: words 4..7
         R *o7 = l7(p), *o6 = l6s(p);
-        constexpr int CP = sizeof(R) == 8 ? 2 : 4;   // passes per chunk (loads in flight: 4 per pass)
+        constexpr int CP = sizeof(R) == 8 ? 2 : 4;   // passes per chunk (4 loads each); f64: 8 in flight is the measured optimum
         for (int q = 0; q < 16 / CP; ++q) {
-            R *in = A + 16;  // level-6 registers: dead here, rewritten by load_l6()
+            R *in = A;       // levels 2..5: dead here, recomputed by the f chain below
 #pragma unroll
             for (int i = 0; i < CP; ++i) {
                 const int e0 = pos + 4 * (CP * q + i);
@@ -273,7 +277,7 @@ struct Fast2Dec {
                 const R v71 = g_bit<R>(in[4 * i + 1], in[4 * i + 3], b7[2 + wq] >> pos, sh);
                 o7[e0] = v70;
                 o7[e0 + 64] = v71;
-                o6[e0] = chk(v70, v71);
+                push_l6(chk(v70, v71), o6, e0);
             }
         }
         set_pa(7, p);
