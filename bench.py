@@ -144,11 +144,14 @@ def main():
     achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9
 
     traffic = None
+    valu = None
     try:  # measured separately with rocprofv3 --pmc (profiles/README.md); only valid for the profiled workload
         with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
             tj = json.load(f).get(args.dtype)
         if tj and tj["frames_per_launch"] == B:
             traffic = (tj["fetch_kib"] + tj["write_kib"]) * 1024.0
+            valu = {"busy_frac": tj.get("valu_busy_frac"), "insts_per_frame": tj.get("valu_insts_per_frame"),
+                    "source": "profiles/r01_k_scl_fast2_b131072.txt (rocprofv3 --pmc)"}
     except Exception:
         traffic = None
 
@@ -191,7 +194,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": dec.kernel_name, "kernel_ms": ms_kernel,
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
                          "note": "path is VALU/LDS-bound, not HBM-bound (SURVEY.md 0.5); see DESIGN.md"},
         }
         if secondary:

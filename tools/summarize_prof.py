@@ -14,12 +14,15 @@ print("## PMC (sum over the chip, per dispatch of the decode kernel, and per fra
 for sub in sorted(glob.glob(f"{d}/pmc*")):
     for f in glob.glob(f"{sub}/*/*_counter_collection.csv"):
         rows = list(csv.DictReader(open(f)))
-        agg = collections.defaultdict(float)
-        disp = set()
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        disp = collections.defaultdict(set)
         for r in rows:
-            if "k_scl" in r["Kernel_Name"] or "k_bp" in r["Kernel_Name"]:
-                agg[r["Counter_Name"]] += float(r["Counter_Value"])
-                disp.add(r["Dispatch_Id"])
-        for c, v in sorted(agg.items()):
-            per = v / max(1, len(disp))
-            print(f"{c:24s} {per:16.6g} per dispatch {per / frames:14.3f} per frame   ({len(disp)} dispatches)")
+            kn = r["Kernel_Name"]
+            if "k_scl" in kn or "k_bp" in kn:
+                kn = kn.split("(")[0].replace("void polar::", "")
+                agg[kn][r["Counter_Name"]] += float(r["Counter_Value"])
+                disp[kn].add(r["Dispatch_Id"])
+        for kn in sorted(agg):
+            for c, v in sorted(agg[kn].items()):
+                per = v / max(1, len(disp[kn]))
+                print(f"{kn:42s} {c:22s} {per:14.6g} per dispatch {per / frames:12.3f} per frame ({len(disp[kn])} dispatches)")
