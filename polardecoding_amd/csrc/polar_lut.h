@@ -110,6 +110,34 @@ struct Lut {
     }
 };
 
+// max(x, 0) (x = +-lambda): the metric penalty |lambda| or 0, one instruction
+__device__ __forceinline__ double posmax(double x)
+{
+    double m;
+    __asm__("v_max_f64 %0, %1, 0" : "=v"(m) : "v"(x));
+    return m;
+}
+__device__ __forceinline__ float posmax(float x)
+{
+    float m;
+    __asm__("v_max_f32_e64 %0, %1, 0" : "=v"(m) : "v"(x));
+    return m;
+}
+
+// max(-x, 0)
+__device__ __forceinline__ double negmax(double x)
+{
+    double m;
+    __asm__("v_max_f64 %0, -%1, 0" : "=v"(m) : "v"(x));
+    return m;
+}
+__device__ __forceinline__ float negmax(float x)
+{
+    float m;
+    __asm__("v_max_f32_e64 %0, -%1, 0" : "=v"(m) : "v"(x));
+    return m;
+}
+
 // min(|a|, |b|) in one instruction (the generic fmin lowering canonicalises both operands first)
 __device__ __forceinline__ double minabs(double a, double b)
 {

@@ -118,34 +118,6 @@ __device__ __forceinline__ double quad_lanes(double x)
 template <int QP>
 __device__ __forceinline__ float quad_lanes(float x) { return __int_as_float(quad_i<QP>(__float_as_int(x))); }
 
-// max(x, 0) (x = +-lambda): the metric penalty |lambda| or 0, one instruction
-__device__ __forceinline__ double posmax(double x)
-{
-    double m;
-    __asm__("v_max_f64 %0, %1, 0" : "=v"(m) : "v"(x));
-    return m;
-}
-__device__ __forceinline__ float posmax(float x)
-{
-    float m;
-    __asm__("v_max_f32_e64 %0, %1, 0" : "=v"(m) : "v"(x));
-    return m;
-}
-
-// max(-x, 0)
-__device__ __forceinline__ double negmax(double x)
-{
-    double m;
-    __asm__("v_max_f64 %0, -%1, 0" : "=v"(m) : "v"(x));
-    return m;
-}
-__device__ __forceinline__ float negmax(float x)
-{
-    float m;
-    __asm__("v_max_f32_e64 %0, -%1, 0" : "=v"(m) : "v"(x));
-    return m;
-}
-
 #ifdef POLAR_MARKS  // static instruction accounting (tools/count_marks.py): comments in the ISA
 #define POLAR_MARK(name) __asm__ volatile("; MARK " name)
 #else

@@ -20,6 +20,7 @@
 // the fallback for shapes without a tuned instantiation; scl_fast.h holds the tuned ones.
 #pragma once
 #include "polar_math.h"
+#include "polar_lut.h"
 
 namespace polar {
 
@@ -82,6 +83,13 @@ __global__ __launch_bounds__(64) void k_scl_generic(SclParams P)
     }
     uint32_t *curw = blw + (size_t)L * NW;
     R *cand = reinterpret_cast<R *>(curw + (size_t)L * NW);
+    // table-driven staircase (polar_lut.h): same bits as polar_math.h's chk / phi, a third of the instructions
+    unsigned char *lut_mem = reinterpret_cast<unsigned char *>(cand + 2 * L);
+    lut_mem += (16 - (reinterpret_cast<uintptr_t>(lut_mem) & 15)) & 15;
+    Lut<R>::build(lut_mem, lane, 64);
+    Lut<R> lut;
+    lut.bind(lut_mem);
+    __syncthreads();
     auto ld = [](const R *q) -> R {
         if constexpr (GA) return ld_bypass(q);
         else return *q;
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(64) void k_scl_generic(SclParams P)
                 if (p < act) {
                     const R *src = (t + 1 == n) ? ch : alpha + (size_t)ptr_get<LOGL>(ptrA, t + 1) * N + (2 << t);
                     R *out = alpha + (size_t)p * N + h;
-                    for (int e = pos; e < h; e += S) out[e] = chk<R>(ld(src + e), ld(src + e + h));
+                    for (int e = pos; e < h; e += S) out[e] = chk_lut<R>(ld(src + e), ld(src + e + h), lut);
                     ptrA = ptr_set<LOGL>(ptrA, t, p);
                 }
                 __syncthreads();
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(64) void k_scl_generic(SclParams P)
             if (P.sc_mode) {
                 bit = (!frozen && lam < R(0)) ? 1 : 0;  // SC_128.c:426-431
             } else if (frozen) {
-                if (p < act) PM += phi<R>(lam, 0);  // SCL_1024.c:601-604, :662-665
+                if (p < act) PM += lut.tabv(lam) + negmax(lam);  // PHI(.,0), SCL_1024.c:601-604, :662-665
             } else if (act < L) {
                 // phase 1: every path forks, clone k -> k + act (SCL_1024.c:586-600)
                 const bool is_new = (p >= act) && (p < 2 * act);
@@ -158,16 +166,17 @@ __global__ __launch_bounds__(64) void k_scl_generic(SclParams P)
                 if (is_new) {
                     for (int w = 1 + pos; w < NW; w += S) blw[p * NW + w] = blw[sg * NW + w];
                     bit = 1;
-                    PM = pm_s + phi<R>(lam_s, 1);
+                    PM = pm_s + (lut.tabv(lam_s) + posmax(lam_s));
                 } else if (p < act) {
-                    PM = PM + phi<R>(lam, 0);
+                    PM = PM + (lut.tabv(lam) + negmax(lam));
                 }
                 act *= 2;
                 __syncthreads();
             } else {
                 // phase 2: keep the L best of 2L candidates (SCL_1024.c:610-661)
-                const R c0 = PM + phi<R>(lam, 0);
-                const R c1 = PM + phi<R>(lam, 1);
+                const R tt = lut.tabv(lam);
+                const R c0 = PM + (tt + negmax(lam));
+                const R c1 = PM + (tt + posmax(lam));
                 if (pos == 0) {
                     cand[p] = c0;
                     cand[p + L] = c1;
@@ -332,7 +341,7 @@ template <typename R, int LOGL>
 constexpr size_t scl_generic_lds_bytes(int N, bool ga)
 {
     return (ga ? 0 : sizeof(R) * (size_t)N * (1 + (1 << LOGL))) + 2 * sizeof(uint32_t) * (size_t)(N / 32) * (1 << LOGL) +
-           sizeof(R) * 2 * (1 << LOGL);
+           sizeof(R) * 2 * (1 << LOGL) + 16 + Lut<R>::bytes;
 }
 
 }  // namespace polar
