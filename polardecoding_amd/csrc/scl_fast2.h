@@ -427,6 +427,7 @@ struct Fast2Dec {
     __device__ __forceinline__ void decide(int o, bool frozen, R lam)
     {
         const int j = 8 * o + K;
+        POLAR_MARK("d2_begin");
         uint32_t crcw = 0;
         if (CRC_ON && !frozen) crcw = crct[j];
         uint32_t bit = 0;
@@ -441,8 +442,10 @@ struct Fast2Dec {
                 PM += bit ? ph1 : ph0;
                 ++logact;
             } else {
+                POLAR_MARK("d2_phase2");
                 const R c0 = PM + ph0, c1 = PM + ph1;
                 const uint32_t mask = survivors(c0, c1);
+                POLAR_MARK("d2_rank_end");
                 const uint32_t m0 = mask & 0xFFu, m1 = mask >> 8;
                 const uint32_t m_both = m0 & m1, m_dead = ~(m0 | m1) & 0xFFu;
                 if (__popc(mask) < L) fl |= 0x1u;  // median tie in this lane's codeword
@@ -451,6 +454,7 @@ struct Fast2Dec {
                     bit = (!s0 && s1) ? 1u : 0u;  // no codeword forks: every slot keeps exactly one branch
                     PM = bit ? c1 : c0;
                 } else {
+                    POLAR_MARK("d2_fork");
                     // m-th both-survivor (ascending slot) forks into the m-th dead slot (:636-661), per codeword
                     const bool dead = !s0 && !s1;
                     const int myrank = __popc(m_dead & ((1u << p) - 1u));
@@ -470,9 +474,12 @@ struct Fast2Dec {
                     else { bit = 0; PM = c0; }  // tie rule: un-refilled dead slot continues as its 0-branch
                 }
             }
+            POLAR_MARK("d2_fork_end");
             if (CRC_ON) crc ^= bit ? crcw : 0u;
         }
+        POLAR_MARK("d2_setbit");
         set_bit_k<K>(o, bit);
+        POLAR_MARK("d2_end");
     }
 
     // ---- octets whose first seven leaves are frozen: breadth-first (all partner bits are 0) ----
