@@ -7,11 +7,26 @@
 // decision (:417-425).  Dropping the dead rows leaves (2(n-1)+1) N reals = 152 KB for N = 1024 in
 // f64, which is what lets a whole f64 codeword sit in one CU's 160 KB LDS.
 // Stage order, operand order inside CHK and inside the sums are the reference's.
+//
+// Synchronisation: a wavefront's 64 butterflies of a stage touch 128 elements.  With butterfly b = 64w + x
+// the stages 0..6 of wave w stay inside elements [128w, 128w + 128) ("map A"); for the stages 7..n-1 the wave
+// takes instead the elements whose low 7 bits lie in a 2^(14-n)-wide window, all high bits ("map B"), which is
+// closed under those stages.  Consecutive stages under the same map exchange data only inside one wave (LDS
+// executes a wave's operations in order), so the workgroup barrier is needed only where the map changes:
+// twice per iteration for N = 1024 instead of 18 times, and the waves of a codeword drift apart enough to
+// overlap one wave's table reads with another's arithmetic.
 #pragma once
 #include "polar_math.h"
 #include "polar_lut.h"
 
 namespace polar {
+
+// The stages are latency-bound chains (2 waves per SIMD in f64): the one-round-trip CHK wins over the compact one.
+#ifdef POLAR_BP_LUT2
+#define BP_CHK chk_lut
+#else
+#define BP_CHK chk_lut1
+#endif
 
 struct BpParams {
     const void *in;          // [B][N] double or float (LLR, or y when sigma > 0)
@@ -20,6 +35,24 @@ struct BpParams {
     const uint32_t *frozen;  // [N/32]
     int N, n, B, iters;
 };
+
+// first element of butterfly bb in stage i (the partner is 2^i further)
+__device__ __forceinline__ int bp_elem(int bb, int i, int n)
+{
+    if (i < 7) return ((bb >> i) << (i + 1)) | (bb & ((1 << i) - 1));
+    const int lo_bits = 14 - n, t = i - 7;
+    const int x = bb & 63, c = bb >> 6;
+    const int h = x >> lo_bits;
+    const int hi = ((h >> t) << (t + 1)) | (h & ((1 << t) - 1));
+    return (hi << 7) | (c << lo_bits) | (x & ((1 << lo_bits) - 1));
+}
+
+// barrier between two consecutive stages: workgroup-wide where the element map changes, else wave-local
+__device__ __forceinline__ void bp_sync(int stage_a, int stage_b)
+{
+    if ((stage_a < 7) != (stage_b < 7)) __syncthreads();
+    else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
 
 template <typename R, typename IN>
 __global__ __launch_bounds__(512) void k_bp(BpParams P)
@@ -58,7 +91,7 @@ __global__ __launch_bounds__(512) void k_bp(BpParams P)
             for (int i = 0; i + 1 < n; ++i) {
                 const int s = 1 << i;
                 for (int b = tid; b < N / 2; b += nt) {
-                    const int j = ((b >> i) << (i + 1)) | (b & (s - 1));
+                    const int j = bp_elem(b, i, n);
                     R r0, r1;
                     if (i == 0) {
                         r0 = ((P.frozen[j >> 5] >> (j & 31)) & 1) ? R(999) : R(0);
@@ -69,18 +102,18 @@ __global__ __launch_bounds__(512) void k_bp(BpParams P)
                     }
                     const R *lrow = (i + 1 == n) ? ch : lm + (size_t)i * N;
                     const R l0 = lrow[j], l1 = lrow[j + s];
-                    const R a = chk_lut<R>(r0, l1 + r1, lut);
-                    const R c = r1 + chk_lut<R>(r0, l0, lut);
+                    const R a = BP_CHK<R>(r0, l1 + r1, lut);
+                    const R c = r1 + BP_CHK<R>(r0, l0, lut);
                     rm[(size_t)i * N + j] = a;
                     rm[(size_t)i * N + j + s] = c;
                 }
-                __syncthreads();
+                bp_sync(i, i + 1);  // next: R stage i+1, or L stage n-1 = i+1
             }
             // L sweep (BP_1024.c:406-415); l[0] is needed only for the final decision
             for (int i = n - 1; i >= (last ? 0 : 1); --i) {
                 const int s = 1 << i;
                 for (int b = tid; b < N / 2; b += nt) {
-                    const int j = ((b >> i) << (i + 1)) | (b & (s - 1));
+                    const int j = bp_elem(b, i, n);
                     R r0, r1;
                     bool f0 = false, f1 = false;
                     if (i == 0) {
@@ -94,8 +127,8 @@ __global__ __launch_bounds__(512) void k_bp(BpParams P)
                     }
                     const R *lrow = (i + 1 == n) ? ch : lm + (size_t)i * N;
                     const R l0 = lrow[j], l1 = lrow[j + s];
-                    const R a = chk_lut<R>(l0, l1 + r1, lut);
-                    const R c = l1 + chk_lut<R>(r0, l0, lut);
+                    const R a = BP_CHK<R>(l0, l1 + r1, lut);
+                    const R c = l1 + BP_CHK<R>(r0, l0, lut);
                     if (i > 0) {
                         lm[(size_t)(i - 1) * N + j] = a;
                         lm[(size_t)(i - 1) * N + j + s] = c;
@@ -107,9 +140,10 @@ __global__ __launch_bounds__(512) void k_bp(BpParams P)
                         if (b1) atomicOr(&obits[(j + s) >> 5], 1u << ((j + s) & 31));
                     }
                 }
-                __syncthreads();
+                if (i > 0) bp_sync(i, i - 1);  // after L stage 1 comes R stage 0 of the next iteration
             }
         }
+        __syncthreads();
         for (int i = tid; i < NW; i += nt) P.out_bits[(size_t)frame * NW + i] = obits[i];
         __syncthreads();
     }

@@ -18,6 +18,7 @@
 #include "scl_fast.h"
 #include "scl_fast2.h"
 #include "scl_generic.h"
+#include "scl_big.h"
 
 namespace {
 
@@ -156,10 +157,39 @@ int launch_scl_v(polar_ctx *c, const polar::SclParams &P)
     return POLAR_OK;
 }
 
-// LDS-resident levels when they fit (160 KB per CU), else the global-scratch variant
+// big lists / long codes: low LLR levels in LDS, the rest in a per-wave scratch slice (scl_big.h)
+template <typename R, typename IN, int LOGL>
+int launch_big(polar_ctx *c, const polar::SclParams &P)
+{
+    using Cfg = polar::BigCfg<R, LOGL>;
+    auto kern = polar::k_scl_big<R, IN, LOGL>;
+    const size_t lds = Cfg::lds_bytes;
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, lds));
+    if (occ < 1) occ = 1;
+    if (occ > 8) occ = 8;
+    int grid = std::min<long long>((long long)P.B, (long long)occ * c->num_cu);
+    if (grid < 1) grid = 1;
+    polar::SclParams Q = P;
+    int rc = ensure(c, c->scratch, Cfg::scratch_bytes(P.N) * (size_t)grid);
+    if (rc) return rc;
+    Q.scratch = c->scratch.p;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, c->stream, Q);
+    HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
+// scl_big.h for SCL / CA-SCL with N >= 512, L >= 2 (shapes without a tuned kernel); else the generic kernel,
+// LDS-resident when the levels fit (160 KB per CU), global-scratch variant otherwise
 template <typename R, typename IN, int LOGL>
 int launch_scl(polar_ctx *c, const polar::SclParams &P)
 {
+    if constexpr (LOGL >= 1) {
+        const bool xw_fits = (size_t)(P.N / 32) * 4 <= sizeof(R) * 64 * (size_t)(1 << LOGL);
+        if (!c->force_generic && !P.sc_mode && P.n >= 9 && xw_fits) return launch_big<R, IN, LOGL>(c, P);
+    }
     if (polar::scl_generic_lds_bytes<R, LOGL>(P.N, false) <= 160 * 1024 && !c->force_spill)
         return launch_scl_v<R, IN, LOGL, false>(c, P);
     return launch_scl_v<R, IN, LOGL, true>(c, P);
@@ -246,7 +276,7 @@ int launch_fast_n(polar_ctx *c, const polar::SclParams &P, bool crc)
 bool fast_ok(const polar_ctx *c, int in_is_f32)
 {
     const polar_cfg &g = c->cfg;
-    if (c->force_generic) return false;
+    if (c->force_generic || c->force_spill) return false;
     if (g.algo != POLAR_ALGO_SCL && g.algo != POLAR_ALGO_CASCL) return false;
     if (g.L != 8 || (g.N != 1024 && g.N != 128)) return false;
     if (g.dtype == POLAR_F64 && in_is_f32) return false;
@@ -480,6 +510,17 @@ int polar_create(const polar_cfg *cfg, polar_ctx **out)
     if (const char *e = getenv("POLAR_FORCE_GENERIC")) c->force_generic = (e[0] == '1');
     if (const char *e = getenv("POLAR_FORCE_SPILL")) c->force_spill = (e[0] == '1');
     if (const char *e = getenv("POLAR_FAST2")) c->use_fast2 = (e[0] != '0');
+    {   // mirrors launch_scl's choice
+        const size_t rs = cfg->dtype == POLAR_F32 ? 4 : 8;
+        const size_t lut = cfg->dtype == POLAR_F32 ? polar::Lut<float>::bytes : polar::Lut<double>::bytes;
+        const size_t gen_lds = rs * (size_t)N * (1 + L) + 8 * (size_t)(N / 32) * L + rs * 2 * L + 16 + lut;
+        (void)gen_lds;
+        if (cfg->algo != POLAR_ALGO_BP && cfg->algo != POLAR_ALGO_SC && !c->force_generic && c->n >= 9 &&
+            L >= 2 && (size_t)(N / 32) * 4 <= rs * 64 * (size_t)L) {
+            snprintf(nm, sizeof nm, "k_scl_big<%s,L=%d>", cfg->dtype == POLAR_F32 ? "float" : "double", L);
+            c->kernel_name = nm;
+        }
+    }
     if (fast_ok(c, cfg->dtype == POLAR_F32)) {
         snprintf(nm, sizeof nm, "k_scl_fast%s<%s,N=%d,L=8>", (N == 1024 && c->use_fast2) ? "2" : "",
                  cfg->dtype == POLAR_F32 ? "float" : "double", N);

@@ -1,0 +1,368 @@
+// scl_big.h -- SCL / CA-SCL for shapes whose LLR levels do not fit a CU's LDS ("LLRs spill HBM": BASELINE
+// config 5, N = 4096 L = 32; also N = 1024 L = 32 in f64).  Same algorithm and operation order as
+// scl_generic.h (reference: SCLdecode, SCL_1024.c:560-674; CASCL, CASCL_1024_L8.c:613-755), other storage:
+//
+//   One codeword per wavefront; lane = (path p, position pos), S = 64 / L lanes per path.
+//   LLR level t <= 5 (the 63 lowest values of a path): LDS, lowA[L][64], level t at offset 2^t.
+//   LLR level t >= 6: per-wave slice of a global scratch buffer, hiA[L][N]; channel LLRs chg[N].
+//     Written with plain stores (write-through to L2), read back with sc1 loads, vmcnt drained in between.
+//   Partial sums, bit-packed (level t, element e <-> bit 2^t + e): bits < 32 in a register, levels 5..7 in
+//     LDS, levels >= 8 in the scratch slice.
+//
+//   Both the LLR levels AND the saved left-child partial sums are shared lazily between a path and its clones
+//   through per-level pointer tables (ptrA / ptrB, 5 bits per level): a fork copies two 64-bit words, never a
+//   row.  (The reference clones the whole factor graph, SCL_1024.c:451-478.)
+//
+//   Levels >= 6 are evaluated one path at a time with all 64 lanes on consecutive elements (coalesced 512 B
+//   rows); levels <= 5 by the path's own S lanes.
+//
+//   Pruning: candidate (p, b) is owned by lane p*S + b.  Every owner counts #{m : c_m <= c_own} over the 2L
+//   keys broadcast from LDS; "count <= L" is the reference's strict "< median" (SCL_1024.c:610-632).  The
+//   m-th both-survivor is paired with the m-th dead slot through a rank table in LDS (:636-661).
+#pragma once
+#include "polar_math.h"
+#include "polar_lut.h"
+#include "scl_generic.h"
+
+namespace polar {
+
+__device__ __forceinline__ uint32_t ld_bypass(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <typename R, int LOGL>
+struct BigCfg {
+    static constexpr int L = 1 << LOGL;
+    static constexpr int S = 64 / L;
+    static constexpr int TL = 5;           // highest LLR level kept in LDS
+    static constexpr int LOW = 64;         // reals per path in LDS
+    static constexpr int WL = 8;           // partial-sum words per path in LDS (levels 5..7)
+    struct __attribute__((aligned(16))) State { uint64_t ptrA, ptrB; R c1; uint32_t crc, bl0; };
+    static constexpr size_t lds_bytes = sizeof(R) * (size_t)L * LOW + 2 * sizeof(uint32_t) * (size_t)L * WL +
+                                        sizeof(R) * 2 * L + sizeof(int) * L + sizeof(State) * L + 32 + Lut<R>::bytes;
+    // scratch per wave, in bytes: chg[N] + hiA[L][N] reals, then gbl[L][N/32] + gcur[L][N/32] words
+    static constexpr size_t scratch_bytes(int N) { return sizeof(R) * (size_t)(L + 1) * N + 2 * sizeof(uint32_t) * (size_t)L * (N / 32); }
+};
+
+template <typename R, typename IN, int LOGL>
+__global__ __launch_bounds__(64) void k_scl_big(SclParams P)
+{
+    using Cfg = BigCfg<R, LOGL>;
+    using State = typename Cfg::State;
+    constexpr int L = Cfg::L, S = Cfg::S, LOW = Cfg::LOW, WL = Cfg::WL;
+    static_assert(S >= 2, "one candidate per lane needs 2L <= 64");
+    const int N = P.N, n = P.n, NW = N >> 5;
+    const int lane = threadIdx.x;
+    const int p = lane / S, pos = lane % S;
+    const uint64_t below = (1ull << (p * S)) - 1ull;   // lanes of lower-numbered paths
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    R *lowA = reinterpret_cast<R *>(smem);
+    uint32_t *blw = reinterpret_cast<uint32_t *>(lowA + (size_t)L * LOW);
+    uint32_t *curw = blw + L * WL;
+    R *cand = reinterpret_cast<R *>(curw + L * WL);
+    int *tbl = reinterpret_cast<int *>(cand + 2 * L);
+    unsigned char *st_mem = reinterpret_cast<unsigned char *>(tbl + L);
+    st_mem += (16 - (reinterpret_cast<uintptr_t>(st_mem) & 15)) & 15;
+    State *st = reinterpret_cast<State *>(st_mem);
+    unsigned char *lut_mem = reinterpret_cast<unsigned char *>(st + L);
+    Lut<R>::build(lut_mem, lane, 64);
+    Lut<R> lut;
+    lut.bind(lut_mem);
+
+    unsigned char *slice = reinterpret_cast<unsigned char *>(P.scratch) + (size_t)blockIdx.x * Cfg::scratch_bytes(N);
+    R *chg = reinterpret_cast<R *>(slice);
+    R *hiA = chg + N;
+    uint32_t *gbl = reinterpret_cast<uint32_t *>(hiA + (size_t)L * N);
+    uint32_t *gcur = gbl + (size_t)L * NW;
+    __syncthreads();
+
+    for (int frame = blockIdx.x; frame < P.B; frame += gridDim.x) {
+        {   // channel LLRs (SCL_1024.c:574-578)
+            const IN *src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
+            for (int i = lane; i < N; i += 64) {
+                double v = (double)src[i];
+                if (P.sigma > 0) v = llr_from_y(v, P.sigma);
+                chg[i] = (R)v;
+            }
+        }
+        __syncthreads();
+
+        R PM = R(0);
+        uint64_t ptrA = 0, ptrB = 0;
+        uint32_t crc = 0, bl0 = 0, cur0 = 0, fl = 0, fw = 0;
+        int act = 1;
+
+        // ---- level t >= 6 from level t+1, one path at a time, 64 consecutive elements per pass ----
+        auto bulk = [&](int t, bool gstep) {
+            const int h = 1 << t;
+            const int my_src = (t + 1 == n) ? 0 : ptr_get<LOGL>(ptrA, t + 1);
+            const int my_bits = ptr_get<LOGL>(ptrB, t);
+            // work item = (path q, pass k): elements e = 64k + lane of path q.  U items are loaded before the
+            // first is used, so that U round trips to L2 overlap instead of queueing behind each other.
+            constexpr int U = 4;
+            const int lp = t - 6, per = 1 << lp, total = act << lp;
+            for (int it = 0; it < total; it += U) {
+                R a[U], b[U];
+                uint32_t wv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = min(it + u, total - 1);   // clamp: the tail repeats the last item
+                    const int q = idx >> lp, e = ((idx & (per - 1)) << 6) + lane;
+                    const int ss = __builtin_amdgcn_readlane(my_src, q * S);
+                    const R *src = (t + 1 == n) ? chg : hiA + (size_t)ss * N + 2 * h;
+                    a[u] = ld_bypass(src + e);
+                    b[u] = ld_bypass(src + e + h);
+                    if (gstep) {
+                        const int bs = __builtin_amdgcn_readlane(my_bits, q * S);
+                        wv[u] = (t >= 8) ? ld_bypass(gbl + (size_t)bs * NW + ((h + e) >> 5)) : blw[bs * WL + ((h + e) >> 5)];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = min(it + u, total - 1);
+                    const int q = idx >> lp, e = ((idx & (per - 1)) << 6) + lane;
+                    R *out = hiA + (size_t)q * N + h;
+                    out[e] = gstep ? gfun<R>(a[u], b[u], (wv[u] >> (e & 31)) & 1) : chk_lut<R>(a[u], b[u], lut);
+                }
+            }
+            if (p < act) ptrA = ptr_set<LOGL>(ptrA, t, p);
+            __syncthreads();
+        };
+        // ---- level t <= 5 from level t+1 by the path's own lanes ----
+        auto low = [&](int t, bool gstep) {
+            const int h = 1 << t;
+            if (p < act) {
+                const int ss = ptr_get<LOGL>(ptrA, t + 1);
+                R *out = lowA + p * LOW + h;
+                uint32_t wv = bl0 >> h;  // t < 5: bit 2^t + e of the register word
+                if (gstep && t == 5) wv = blw[ptr_get<LOGL>(ptrB, 5) * WL + 1];
+                if (t == Cfg::TL) {
+                    const R *src = hiA + (size_t)ss * N + 2 * h;
+                    constexpr int U = (32 / S) < 8 ? (32 / S) : 8;   // loads in flight per lane
+                    for (int e0 = pos; e0 < h; e0 += S * U) {
+                        R a[U], b[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            a[u] = ld_bypass(src + e0 + u * S);
+                            b[u] = ld_bypass(src + e0 + u * S + h);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int e = e0 + u * S;
+                            out[e] = gstep ? gfun<R>(a[u], b[u], (wv >> e) & 1) : chk_lut<R>(a[u], b[u], lut);
+                        }
+                    }
+                } else {
+                    const R *src = lowA + ss * LOW + 2 * h;
+                    for (int e = pos; e < h; e += S) {
+                        const R a = src[e], b = src[e + h];
+                        out[e] = gstep ? gfun<R>(a, b, (wv >> e) & 1) : chk_lut1<R>(a, b, lut);
+                    }
+                }
+                ptrA = ptr_set<LOGL>(ptrA, t, p);
+            }
+            __asm__ volatile("" ::: "memory");  // LDS executes one wave's operations in order
+        };
+
+        for (int j = 0; j < N; ++j) {
+            // ================= LLR of leaf j for every active path =================
+            int tf = n - 1;
+            if (j > 0) {
+                const int d = __builtin_ctz((unsigned)j);
+                if (d > Cfg::TL) bulk(d, true);
+                else low(d, true);
+                tf = d - 1;
+            }
+            for (int t = tf; t >= 0; --t) {
+                if (t > Cfg::TL) bulk(t, false);
+                else low(t, false);
+            }
+            const R lam = (p < act) ? lowA[p * LOW + 1] : R(0);
+
+            // ================= decision =================
+            if ((j & 31) == 0) fw = P.frozen[j >> 5];
+            const bool frozen = (fw >> (j & 31)) & 1;
+            int bit = 0;
+            if (frozen) {
+                if (p < act) PM += lut.tabv(lam) + negmax(lam);  // PHI(.,0), SCL_1024.c:601-604, :662-665
+            } else if (act < L) {
+                // phase 1: every path forks, clone k -> k + act (SCL_1024.c:586-600)
+                const bool is_new = (p >= act) && (p < 2 * act);
+                const int sg = is_new ? p - act : p;
+                const int sl = sg * S + pos;
+                const R lam_s = __shfl(lam, sl);
+                const R pm_s = __shfl(PM, sl);
+                ptrA = __shfl(ptrA, sl);
+                ptrB = __shfl(ptrB, sl);
+                crc = __shfl(crc, sl);
+                bl0 = __shfl(bl0, sl);
+                if (is_new) {
+                    bit = 1;
+                    PM = pm_s + (lut.tabv(lam_s) + posmax(lam_s));
+                } else if (p < act) {
+                    PM = PM + (lut.tabv(lam) + negmax(lam));
+                }
+                act *= 2;
+            } else {
+                // phase 2: keep the L best of 2L candidates (SCL_1024.c:610-661)
+                const R tt = lut.tabv(lam);
+                const R c0 = PM + (tt + negmax(lam));
+                const R c1 = PM + (tt + posmax(lam));
+                const R mine = (pos == 0) ? c0 : c1;
+                if (pos < 2) cand[2 * p + pos] = mine;
+                __asm__ volatile("" ::: "memory");
+                // strict "< med" with med = (L+1)-th smallest  <=>  #{m : c_m <= c} <= L
+                int cnt = 0;
+#pragma unroll 8
+                for (int m = 0; m < 2 * L; m += 2) {
+                    const R v0 = cand[m], v1 = cand[m + 1];
+                    cnt += (v0 <= mine);
+                    cnt += (v1 <= mine);
+                }
+                const bool surv = cnt <= L;
+                const uint64_t m_s0 = __ballot(pos == 0 && surv);
+                const uint64_t m_s1 = __ballot(pos == 1 && surv) >> 1;   // aligned to the lead lanes
+                const uint64_t m_both = m_s0 & m_s1;
+                const uint64_t m_dead = __ballot(pos == 0) & ~(m_s0 | m_s1);
+                if (__popcll(m_s0) + __popcll(m_s1) < L) fl |= 0x1u;  // median tie ("Oops!", :621-622)
+                const bool s0 = (m_s0 >> (p * S)) & 1, s1 = (m_s1 >> (p * S)) & 1;
+                // m-th both-survivor (ascending slot) forks into the m-th dead slot (:636-661)
+                const int nboth = __popcll(m_both);
+                bool refilled = false;
+                if (nboth) {
+                    if (s0 && s1 && pos == 0) tbl[__popcll(m_both & below)] = p;
+                    if (pos == 0) {
+                        State me;
+                        me.ptrA = ptrA; me.ptrB = ptrB; me.c1 = c1; me.crc = crc; me.bl0 = bl0;
+                        st[p] = me;
+                    }
+                    __asm__ volatile("" ::: "memory");
+                    const int rank_dead = __popcll(m_dead & below);
+                    refilled = !s0 && !s1 && rank_dead < nboth;
+                    if (refilled) {
+                        const State src = st[tbl[rank_dead]];
+                        ptrA = src.ptrA; ptrB = src.ptrB; crc = src.crc; bl0 = src.bl0;
+                        PM = src.c1;
+                        bit = 1;
+                    }
+                }
+                if (!refilled) {
+                    if (s0) {
+                        bit = 0;  // class 0 or the staying half of class 2
+                        PM = c0;
+                    } else if (s1) {
+                        bit = 1;
+                        PM = c1;
+                    } else {
+                        bit = 0;  // tie rule: an un-refilled dead slot continues as its 0-branch
+                        PM = c0;
+                    }
+                }
+                __asm__ volatile("" ::: "memory");
+            }
+
+            // ================= partial sums (updateBit, SCL_1024.c:424-448) =================
+            if (P.crc_tab && bit) crc ^= P.crc_tab[j];
+            cur0 = (uint32_t)bit;
+            int t = 0;
+            while (t < n && ((j >> t) & 1)) {
+                if (t < 5) {
+                    const int h = 1 << t;
+                    const uint32_t mask = (1u << h) - 1u;
+                    const uint32_t l = (bl0 >> h) & mask;
+                    const uint32_t c = cur0 & mask;
+                    cur0 = (l ^ c) | (c << h);
+                } else {
+                    const int nw = 1 << (t - 5);
+                    if (t == 5) {
+                        if (pos == 0 && p < act) curw[p * WL] = cur0;
+                        __asm__ volatile("" ::: "memory");
+                    }
+                    if (p < act) {
+                        const int bs = ptr_get<LOGL>(ptrB, t);
+                        if (t < 8) {          // cur_t, bl_t, cur_{t+1} (<= 8 words) all in LDS
+                            for (int w = pos; w < nw; w += S) {
+                                const uint32_t c = curw[p * WL + w];
+                                const uint32_t l = blw[bs * WL + nw + w];
+                                curw[p * WL + w] = l ^ c;
+                                curw[p * WL + w + nw] = c;
+                            }
+                        } else {              // result goes to the scratch slice
+                            for (int w = pos; w < nw; w += S) {
+                                const uint32_t c = (t == 8) ? curw[p * WL + w] : ld_bypass(gcur + (size_t)p * NW + w);
+                                const uint32_t l = ld_bypass(gbl + (size_t)bs * NW + nw + w);
+                                gcur[(size_t)p * NW + w] = l ^ c;
+                                gcur[(size_t)p * NW + w + nw] = c;
+                            }
+                        }
+                    }
+                    if (t < 8) __asm__ volatile("" ::: "memory");
+                    else __syncthreads();
+                }
+                ++t;
+            }
+            if (t < n) {
+                if (t < 5) {
+                    const int h = 1 << t;
+                    const uint32_t mask = (1u << h) - 1u;
+                    bl0 = (bl0 & ~(mask << h)) | ((cur0 & mask) << h);
+                } else {
+                    const int nw = 1 << (t - 5);
+                    if (p < act) {
+                        if (t == 5) {
+                            if (pos == 0) blw[p * WL + 1] = cur0;
+                        } else if (t < 8) {
+                            for (int w = pos; w < nw; w += S) blw[p * WL + nw + w] = curw[p * WL + w];
+                        } else {
+                            for (int w = pos; w < nw; w += S)
+                                gbl[(size_t)p * NW + nw + w] = (t == 8) ? curw[p * WL + w] : ld_bypass(gcur + (size_t)p * NW + w);
+                        }
+                        ptrB = ptr_set<LOGL>(ptrB, t, p);
+                    }
+                    if (t < 8) __asm__ volatile("" ::: "memory");
+                    else __syncthreads();
+                }
+            }
+        }
+
+        // ================= choose the path (SCL_1024.c:667-674; CASCL_1024_L8.c:725-755) =================
+        const bool pass = (P.crc_tab != nullptr) && (crc == 0);
+        const bool any = __ballot(pass && p < act) != 0ull;
+        int best = -1;
+        R best_pm = R(0);
+        for (int q = 0; q < act; ++q) {
+            const R pq = __shfl(PM, q * S);
+            const int okq = __shfl((int)(any ? pass : true), q * S);
+            if (okq && (best < 0 || pq < best_pm)) {
+                best = q;
+                best_pm = pq;
+            }
+        }
+        if (any) fl |= 0x2u;
+        // x_hat of the chosen path: root partial sums (scratch slice, n >= 9); u_hat = x_hat * F^{(x)n} in LDS
+        uint32_t *xw = reinterpret_cast<uint32_t *>(lowA);
+        for (int w = lane; w < NW; w += 64) {
+            uint32_t x = ld_bypass(gcur + (size_t)best * NW + w);
+            x ^= (x >> 1) & 0x55555555u;
+            x ^= (x >> 2) & 0x33333333u;
+            x ^= (x >> 4) & 0x0F0F0F0Fu;
+            x ^= (x >> 8) & 0x00FF00FFu;
+            x ^= (x >> 16) & 0x0000FFFFu;
+            xw[w] = x;
+        }
+        __syncthreads();
+        for (int s = 5; s < n; ++s) {
+            const int hw = 1 << (s - 5);
+            for (int w = lane; w < NW; w += 64)
+                if (!(w & hw)) xw[w] ^= xw[w + hw];
+            __syncthreads();
+        }
+        for (int w = lane; w < NW; w += 64) P.out_bits[(size_t)frame * NW + w] = xw[w];
+        if (lane == 0) {
+            if (P.pm) P.pm[frame] = (double)best_pm;
+            if (P.flags) P.flags[frame] = fl;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace polar

@@ -121,6 +121,42 @@ def test_forced_spill_matches_golden(monkeypatch):
         assert np.array_equal(pm, g["pm"][sel])
 
 
+def test_big_list_kernel_matches_golden(monkeypatch):
+    """scl_big.h (low levels in LDS, the rest in scratch, lazily shared partial sums) forced onto the
+    reference's own N = 1024 L = 8 programs: same bits and path metrics as the compiled reference."""
+    import polardecoding_amd as pa
+    monkeypatch.setenv("POLAR_FORCE_SPILL", "1")
+    for name in ("CASCL_1024_L8", "SCL_1024"):
+        g = load_golden(name)
+        dec = make(name)
+        assert "k_scl_big" in dec.kernel_name
+        for s in np.unique(g["sigma"]):
+            sel = g["sigma"] == s
+            uh, pm, fl = dec.decode_batch_y(g["y"][sel], float(s))
+            assert np.array_equal(uh, g["u_hat"][sel].astype(np.int32))
+            assert np.array_equal(pm, g["pm"][sel])
+
+
+@pytest.mark.parametrize("L", [2, 4, 16, 32])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_big_list_kernel_list_sizes_vs_oracle(L, dtype, oracle, monkeypatch):
+    import polardecoding_amd as pa
+    monkeypatch.setenv("POLAR_FORCE_SPILL", "1")
+    N, K = 1024, 512
+    code = oracle.Code(N, K, pa.CRC24C_TAPS)
+    sim = oracle.Sim(77 + L)
+    sig = oracle.sigma_from_db(1.0)
+    us, ys = sim.frames(code, sig, 24)
+    llr = np.stack([oracle.llr_from_y(y, sig) for y in ys]).astype(np.float32).astype(np.float64)
+    ref_uh, ref_pm, _ = oracle.decode(code, llr, "CASCL", L=L, dtype=dtype)
+    dec = pa.CASCL(N, K, L=L, dtype=pa.F64 if dtype == "f64" else pa.F32)
+    assert "k_scl_big" in dec.kernel_name
+    uh, pm, fl = dec.decode_batch(llr)
+    assert np.array_equal(uh, ref_uh)
+    if dtype == "f64":
+        assert np.array_equal(pm, ref_pm)
+
+
 @pytest.mark.parametrize("name", ["SC_1024", "SCL_1024", "CASCL_1024_L8", "CASCL_128", "BP_128"])
 def test_f32_matches_f32_oracle(name, oracle):
     """The f32 kernels keep the operation order: bit-identical to the oracle's f32 instantiation."""
