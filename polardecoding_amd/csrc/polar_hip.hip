@@ -158,27 +158,39 @@ int launch_scl_v(polar_ctx *c, const polar::SclParams &P)
 }
 
 // big lists / long codes: low LLR levels in LDS, the rest in a per-wave scratch slice (scl_big.h)
-template <typename R, typename IN, int LOGL>
-int launch_big(polar_ctx *c, const polar::SclParams &P)
+template <typename R, typename IN, int LOGL, int TL, int TB>
+int launch_big_v(polar_ctx *c, const polar::SclParams &P)
 {
-    using Cfg = polar::BigCfg<R, LOGL>;
-    auto kern = polar::k_scl_big<R, IN, LOGL>;
+    using Cfg = polar::BigCfg<R, LOGL, TL, TB>;
+    auto kern = polar::k_scl_big<R, IN, LOGL, TL, TB>;
     const size_t lds = Cfg::lds_bytes;
+    const int threads = 64 * Cfg::WAVES;
     HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
     int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, lds));
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds));
     if (occ < 1) occ = 1;
-    if (occ > 8) occ = 8;
-    int grid = std::min<long long>((long long)P.B, (long long)occ * c->num_cu);
+    const long long blocks_needed = ((long long)P.B + Cfg::WAVES - 1) / Cfg::WAVES;
+    int grid = std::min<long long>(blocks_needed, (long long)occ * c->num_cu);
     if (grid < 1) grid = 1;
     polar::SclParams Q = P;
-    int rc = ensure(c, c->scratch, Cfg::scratch_bytes(P.N) * (size_t)grid);
+    int rc = ensure(c, c->scratch, Cfg::scratch_bytes(P.N) * (size_t)grid * Cfg::WAVES);
     if (rc) return rc;
     Q.scratch = c->scratch.p;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, c->stream, Q);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
     return POLAR_OK;
+}
+
+// the LDS / scratch split that measured best per arithmetic type (profiles/README.md); POLAR_BIG_SPLIT=35|46|57 overrides
+template <typename R, typename IN, int LOGL>
+int launch_big(polar_ctx *c, const polar::SclParams &P)
+{
+    static const int split = getenv("POLAR_BIG_SPLIT") ? atoi(getenv("POLAR_BIG_SPLIT")) : 0;
+    const int use = split ? split : (sizeof(R) == 8 ? 35 : 46);
+    if (use == 57) return launch_big_v<R, IN, LOGL, 5, 7>(c, P);
+    if (use == 46) return launch_big_v<R, IN, LOGL, 4, 6>(c, P);
+    return launch_big_v<R, IN, LOGL, 3, 5>(c, P);
 }
 
 // scl_big.h for SCL / CA-SCL with N >= 512, L >= 2 (shapes without a tuned kernel); else the generic kernel,
@@ -187,8 +199,7 @@ template <typename R, typename IN, int LOGL>
 int launch_scl(polar_ctx *c, const polar::SclParams &P)
 {
     if constexpr (LOGL >= 1) {
-        const bool xw_fits = (size_t)(P.N / 32) * 4 <= sizeof(R) * 64 * (size_t)(1 << LOGL);
-        if (!c->force_generic && !P.sc_mode && P.n >= 9 && xw_fits) return launch_big<R, IN, LOGL>(c, P);
+        if (!c->force_generic && !P.sc_mode && P.n >= 9) return launch_big<R, IN, LOGL>(c, P);
     }
     if (polar::scl_generic_lds_bytes<R, LOGL>(P.N, false) <= 160 * 1024 && !c->force_spill)
         return launch_scl_v<R, IN, LOGL, false>(c, P);
@@ -335,8 +346,11 @@ int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sig
         atexit([] {
             unsigned long long h[8];
             (void)hipMemcpy(h, s_dbg, sizeof h, hipMemcpyDeviceToHost);
-            const char *nm[8] = {"prologue", "load ch", "tl+init", "octet_head (d<6)", "octet frozen-prefix", "octet generic",
-                                 "select+store", "octet_head (d>=6, scratch levels)"};
+            const char *nm_fast[8] = {"prologue", "load ch", "tl+init", "octet_head (d<6)", "octet frozen-prefix", "octet generic",
+                                      "select+store", "octet_head (d>=6, scratch levels)"};
+            const char *nm_big[8] = {"prologue+channel", "upper levels t>=6", "upper levels t<6", "LDS levels", "frozen / phase-1 leaf",
+                                     "phase-2 decision", "partial sums", "select+store"};
+            const char **nm = getenv("POLAR_STAMPS_BIG") ? nm_big : nm_fast;
             unsigned long long tot = 0;
             for (int i = 0; i < 8; ++i) tot += h[i];
             for (int i = 0; i < 8; ++i)
@@ -516,7 +530,7 @@ int polar_create(const polar_cfg *cfg, polar_ctx **out)
         const size_t gen_lds = rs * (size_t)N * (1 + L) + 8 * (size_t)(N / 32) * L + rs * 2 * L + 16 + lut;
         (void)gen_lds;
         if (cfg->algo != POLAR_ALGO_BP && cfg->algo != POLAR_ALGO_SC && !c->force_generic && c->n >= 9 &&
-            L >= 2 && (size_t)(N / 32) * 4 <= rs * 64 * (size_t)L) {
+            L >= 2) {
             snprintf(nm, sizeof nm, "k_scl_big<%s,L=%d>", cfg->dtype == POLAR_F32 ? "float" : "double", L);
             c->kernel_name = nm;
         }

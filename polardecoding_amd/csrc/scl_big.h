@@ -2,19 +2,23 @@
 // config 5, N = 4096 L = 32; also N = 1024 L = 32 in f64).  Same algorithm and operation order as
 // scl_generic.h (reference: SCLdecode, SCL_1024.c:560-674; CASCL, CASCL_1024_L8.c:613-755), other storage:
 //
-//   One codeword per wavefront; lane = (path p, position pos), S = 64 / L lanes per path.
-//   LLR level t <= 5 (the 63 lowest values of a path): LDS, lowA[L][64], level t at offset 2^t.
-//   LLR level t >= 6: per-wave slice of a global scratch buffer, hiA[L][N]; channel LLRs chg[N].
+//   One codeword per wavefront (four independent wavefronts per workgroup, sharing the look-up tables);
+//   lane = (path p, position pos), S = 64 / L lanes per path.
+//   LLR level t <= TL (the 2^(TL+1) - 1 lowest values of a path): LDS, lowA[L][2^(TL+1)], level t at offset 2^t.
+//   LLR level t > TL: per-wave slice of a global scratch buffer, hiA[L][N]; channel LLRs chg[N].
 //     Written with plain stores (write-through to L2), read back with sc1 loads, vmcnt drained in between.
-//   Partial sums, bit-packed (level t, element e <-> bit 2^t + e): bits < 32 in a register, levels 5..7 in
-//     LDS, levels >= 8 in the scratch slice.
+//   Partial sums, bit-packed (level t, element e <-> bit 2^t + e): bits < 32 in a register, levels 5..TB in
+//     LDS, levels > TB in the scratch slice.
+//   The decoder is a chain of dependent LDS / L2 round trips, so throughput follows the number of resident
+//   wavefronts, which the LDS footprint sets: TL and TB trade a few more L2 round trips per frame for more
+//   codewords per CU (profiles/README.md).
 //
 //   Both the LLR levels AND the saved left-child partial sums are shared lazily between a path and its clones
 //   through per-level pointer tables (ptrA / ptrB, 5 bits per level): a fork copies two 64-bit words, never a
 //   row.  (The reference clones the whole factor graph, SCL_1024.c:451-478.)
 //
-//   Levels >= 6 are evaluated one path at a time with all 64 lanes on consecutive elements (coalesced 512 B
-//   rows); levels <= 5 by the path's own S lanes.
+//   Levels > TL are evaluated with all 64 lanes on consecutive elements of one path (of 64 / 2^t paths below
+//   level 6): coalesced rows; levels <= TL by the path's own S lanes.
 //
 //   Pruning: candidate (p, b) is owned by lane p*S + b.  Every owner counts #{m : c_m <= c_own} over the 2L
 //   keys broadcast from LDS; "count <= L" is the reference's strict "< median" (SCL_1024.c:610-632).  The
@@ -28,54 +32,78 @@ namespace polar {
 
 __device__ __forceinline__ uint32_t ld_bypass(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <typename R, int LOGL>
+template <typename R, int LOGL, int TLv, int TBv>
 struct BigCfg {
     static constexpr int L = 1 << LOGL;
     static constexpr int S = 64 / L;
-    static constexpr int TL = 5;           // highest LLR level kept in LDS
-    static constexpr int LOW = 64;         // reals per path in LDS
-    static constexpr int WL = 8;           // partial-sum words per path in LDS (levels 5..7)
+    static constexpr int WAVES = 4;                   // codewords per workgroup; they share only the look-up tables
+    static constexpr int TL = TLv;                    // highest LLR level kept in LDS (3..5)
+    static constexpr int TB = TBv;                    // highest partial-sum level kept in LDS (5..7)
+    static constexpr int LOW = (2 << TL) + 1;         // row stride of lowA: odd, so that the paths fall into different banks
+    static constexpr int WLU = 1 << (TB - 4);         // partial-sum words per path in LDS
+    static constexpr int WL = WLU + 1;                // their row stride (odd)
+    static_assert(TL >= 3 && TL <= 5 && TB >= 5 && TB <= 7, "storage split");
     struct __attribute__((aligned(16))) State { uint64_t ptrA, ptrB; R c1; uint32_t crc, bl0; };
-    static constexpr size_t lds_bytes = sizeof(R) * (size_t)L * LOW + 2 * sizeof(uint32_t) * (size_t)L * WL +
-                                        sizeof(R) * 2 * L + sizeof(int) * L + sizeof(State) * L + 32 + Lut<R>::bytes;
+    static constexpr size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+    static constexpr size_t off_blw = align16(sizeof(R) * (size_t)L * LOW);
+    static constexpr size_t off_cur = off_blw + sizeof(uint32_t) * (size_t)L * WL;
+    static constexpr size_t off_cand = align16(off_cur + sizeof(uint32_t) * (size_t)L * WL);
+    static constexpr size_t off_tbl = off_cand + sizeof(R) * 2 * L;
+    static constexpr size_t off_st = align16(off_tbl + sizeof(int) * L);
+    static constexpr size_t wave_bytes = align16(off_st + sizeof(State) * L);
+    static constexpr size_t lds_bytes = wave_bytes * WAVES + Lut<R>::bytes;
     // scratch per wave, in bytes: chg[N] + hiA[L][N] reals, then gbl[L][N/32] + gcur[L][N/32] words
     static constexpr size_t scratch_bytes(int N) { return sizeof(R) * (size_t)(L + 1) * N + 2 * sizeof(uint32_t) * (size_t)L * (N / 32); }
 };
 
-template <typename R, typename IN, int LOGL>
-__global__ __launch_bounds__(64) void k_scl_big(SclParams P)
+// everything a wave wrote (LDS and scratch) is visible to its own later loads; no other wave ever reads it
+__device__ __forceinline__ void wave_sync() { __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
+#ifdef POLAR_STAMPS  // diagnostic build: s_memtime per section, summed per wave, added to P.dbg[]
+#define BIG_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsec[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define BIG_STAMP(i) do { } while (0)
+#endif
+
+template <typename R, typename IN, int LOGL, int TLv, int TBv>
+__global__ __launch_bounds__(256) void k_scl_big(SclParams P)
 {
-    using Cfg = BigCfg<R, LOGL>;
+#ifdef POLAR_STAMPS
+    unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+    using Cfg = BigCfg<R, LOGL, TLv, TBv>;
     using State = typename Cfg::State;
-    constexpr int L = Cfg::L, S = Cfg::S, LOW = Cfg::LOW, WL = Cfg::WL;
+    constexpr int L = Cfg::L, S = Cfg::S, LOW = Cfg::LOW, WL = Cfg::WL, TL = Cfg::TL, TB = Cfg::TB, WAVES = Cfg::WAVES;
     static_assert(S >= 2, "one candidate per lane needs 2L <= 64");
     const int N = P.N, n = P.n, NW = N >> 5;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = lane / S, pos = lane % S;
     const uint64_t below = (1ull << (p * S)) - 1ull;   // lanes of lower-numbered paths
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    R *lowA = reinterpret_cast<R *>(smem);
-    uint32_t *blw = reinterpret_cast<uint32_t *>(lowA + (size_t)L * LOW);
-    uint32_t *curw = blw + L * WL;
-    R *cand = reinterpret_cast<R *>(curw + L * WL);
-    int *tbl = reinterpret_cast<int *>(cand + 2 * L);
-    unsigned char *st_mem = reinterpret_cast<unsigned char *>(tbl + L);
-    st_mem += (16 - (reinterpret_cast<uintptr_t>(st_mem) & 15)) & 15;
-    State *st = reinterpret_cast<State *>(st_mem);
-    unsigned char *lut_mem = reinterpret_cast<unsigned char *>(st + L);
-    Lut<R>::build(lut_mem, lane, 64);
+    unsigned char *mine_mem = smem + (size_t)wave * Cfg::wave_bytes;
+    R *lowA = reinterpret_cast<R *>(mine_mem);
+    uint32_t *blw = reinterpret_cast<uint32_t *>(mine_mem + Cfg::off_blw);
+    uint32_t *curw = reinterpret_cast<uint32_t *>(mine_mem + Cfg::off_cur);
+    R *cand = reinterpret_cast<R *>(mine_mem + Cfg::off_cand);
+    int *tbl = reinterpret_cast<int *>(mine_mem + Cfg::off_tbl);
+    State *st = reinterpret_cast<State *>(mine_mem + Cfg::off_st);
+    unsigned char *lut_mem = smem + (size_t)WAVES * Cfg::wave_bytes;
+    Lut<R>::build(lut_mem, threadIdx.x, blockDim.x);
     Lut<R> lut;
     lut.bind(lut_mem);
 
-    unsigned char *slice = reinterpret_cast<unsigned char *>(P.scratch) + (size_t)blockIdx.x * Cfg::scratch_bytes(N);
+    const int slot = blockIdx.x * WAVES + wave, nslots = gridDim.x * WAVES;
+    unsigned char *slice = reinterpret_cast<unsigned char *>(P.scratch) + (size_t)slot * Cfg::scratch_bytes(N);
     R *chg = reinterpret_cast<R *>(slice);
     R *hiA = chg + N;
     uint32_t *gbl = reinterpret_cast<uint32_t *>(hiA + (size_t)L * N);
     uint32_t *gcur = gbl + (size_t)L * NW;
-    __syncthreads();
+    __syncthreads();   // the tables are built; from here on the waves of a workgroup never meet again
 
-    for (int frame = blockIdx.x; frame < P.B; frame += gridDim.x) {
+    for (int frame = slot; frame < P.B; frame += nslots) {
         {   // channel LLRs (SCL_1024.c:574-578)
             const IN *src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
             for (int i = lane; i < N; i += 64) {
@@ -84,50 +112,89 @@ __global__ __launch_bounds__(64) void k_scl_big(SclParams P)
                 chg[i] = (R)v;
             }
         }
-        __syncthreads();
+        wave_sync();
 
         R PM = R(0);
         uint64_t ptrA = 0, ptrB = 0;
-        uint32_t crc = 0, bl0 = 0, cur0 = 0, fl = 0, fw = 0;
+        uint32_t crc = 0, bl0 = 0, cur0 = 0, fl = 0, fw = 0, ctv = 0;
         int act = 1;
 
-        // ---- level t >= 6 from level t+1, one path at a time, 64 consecutive elements per pass ----
+        // ---- level t > TL from level t+1, all 64 lanes on consecutive elements ----
+        // Paths that share the source buffer (and, for a g step, the partial-sum buffer) would compute the same
+        // row: it is computed once, by the lowest such path ("leader"), and the others point at the leader's row.
+        // Far above the leaves most of the list still shares its ancestors, so this removes most of the work and
+        // of the L2 / HBM traffic of the upper levels without changing a single value.
         auto bulk = [&](int t, bool gstep) {
             const int h = 1 << t;
             const int my_src = (t + 1 == n) ? 0 : ptr_get<LOGL>(ptrA, t + 1);
             const int my_bits = ptr_get<LOGL>(ptrB, t);
-            // work item = (path q, pass k): elements e = 64k + lane of path q.  U items are loaded before the
-            // first is used, so that U round trips to L2 overlap instead of queueing behind each other.
-            constexpr int U = 4;
-            const int lp = t - 6, per = 1 << lp, total = act << lp;
-            for (int it = 0; it < total; it += U) {
-                R a[U], b[U];
-                uint32_t wv[U];
+            // g below level 5 takes its bits from the register word, not from a shared buffer
+            const int key = !gstep ? my_src : (t >= 5) ? (my_src | (my_bits << LOGL)) : (my_src | (int)(((bl0 >> h) & ((1u << h) - 1u)) << LOGL));
+            int leader = p;
+            for (int k = act - 1; k >= 0; --k)
+                if (__builtin_amdgcn_readlane(key, k * S) == key) leader = k;
+            const uint64_t m_lead = __ballot(pos == 0 && p < act && leader == p);
+            const int nlead = __popcll(m_lead);
+            if (pos == 0 && p < act && leader == p) tbl[__popcll(m_lead & below)] = p;
+            __asm__ volatile("" ::: "memory");
+            if (t >= 6) {
+                // work item = (leader q, pass k): elements e = 64k + lane of path q.  U items are loaded before the
+                // first is used, so that U round trips to L2 overlap instead of queueing behind each other.
+                constexpr int U = 4;
+                const int lp = t - 6, per = 1 << lp, total = nlead << lp;
+                for (int it = 0; it < total; it += U) {
+                    R a[U], b[U];
+                    uint32_t wv[U];
+                    int qs[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int idx = min(it + u, total - 1);   // clamp: the tail repeats the last item
-                    const int q = idx >> lp, e = ((idx & (per - 1)) << 6) + lane;
-                    const int ss = __builtin_amdgcn_readlane(my_src, q * S);
-                    const R *src = (t + 1 == n) ? chg : hiA + (size_t)ss * N + 2 * h;
-                    a[u] = ld_bypass(src + e);
-                    b[u] = ld_bypass(src + e + h);
-                    if (gstep) {
-                        const int bs = __builtin_amdgcn_readlane(my_bits, q * S);
-                        wv[u] = (t >= 8) ? ld_bypass(gbl + (size_t)bs * NW + ((h + e) >> 5)) : blw[bs * WL + ((h + e) >> 5)];
+                    for (int u = 0; u < U; ++u) {
+                        const int idx = min(it + u, total - 1);   // clamp: the tail repeats the last item
+                        const int q = __builtin_amdgcn_readfirstlane(tbl[idx >> lp]), e = ((idx & (per - 1)) << 6) + lane;
+                        qs[u] = q;
+                        const int ss = __builtin_amdgcn_readlane(my_src, q * S);
+                        const R *src = (t + 1 == n) ? chg : hiA + (size_t)ss * N + 2 * h;
+                        a[u] = ld_bypass(src + e);
+                        b[u] = ld_bypass(src + e + h);
+                        if (gstep) {
+                            const int bs = __builtin_amdgcn_readlane(my_bits, q * S);
+                            wv[u] = (t > TB) ? ld_bypass(gbl + (size_t)bs * NW + ((h + e) >> 5)) : blw[bs * WL + ((h + e) >> 5)];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int idx = min(it + u, total - 1);
+                        const int e = ((idx & (per - 1)) << 6) + lane;
+                        R *out = hiA + (size_t)qs[u] * N + h;
+                        out[e] = gstep ? gfun<R>(a[u], b[u], (wv[u] >> (e & 31)) & 1) : chk_lut<R>(a[u], b[u], lut);
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int idx = min(it + u, total - 1);
-                    const int q = idx >> lp, e = ((idx & (per - 1)) << 6) + lane;
-                    R *out = hiA + (size_t)q * N + h;
-                    out[e] = gstep ? gfun<R>(a[u], b[u], (wv[u] >> (e & 31)) & 1) : chk_lut<R>(a[u], b[u], lut);
+            } else {
+                // t = 4 or 5 (only when TL < 5): 64 / 2^t leaders per pass, source slots fetched by lane
+                const int total = nlead << t;   // elements over all leaders
+                for (int it = 0; it < total; it += 64) {
+                    const int idx = it + lane;
+                    const bool on = idx < total;
+                    const int q = on ? tbl[idx >> t] : 0, e = idx & (h - 1);
+                    const int ss = __shfl(my_src, q * S);
+                    const R *src = hiA + (size_t)ss * N + 2 * h;
+                    const R a = ld_bypass(src + e), b = ld_bypass(src + e + h);
+                    R r;
+                    if (gstep) {
+                        const uint32_t w0 = __shfl(bl0, q * S);                 // t = 4: bits 16 + e of the register word
+                        const int bs = __shfl(my_bits, q * S);
+                        const uint32_t wv = (t == 5) ? blw[bs * WL + 1] : (w0 >> h);
+                        r = gfun<R>(a, b, (wv >> e) & 1);
+                    } else {
+                        r = chk_lut<R>(a, b, lut);
+                    }
+                    if (on) hiA[(size_t)q * N + h + e] = r;
                 }
             }
-            if (p < act) ptrA = ptr_set<LOGL>(ptrA, t, p);
-            __syncthreads();
+            if (p < act) ptrA = ptr_set<LOGL>(ptrA, t, leader);
+            wave_sync();
+            BIG_STAMP((t >= 6) ? 1 : 2);
         };
-        // ---- level t <= 5 from level t+1 by the path's own lanes ----
+        // ---- level t <= TL from level t+1 by the path's own lanes ----
         auto low = [&](int t, bool gstep) {
             const int h = 1 << t;
             if (p < act) {
@@ -135,9 +202,10 @@ __global__ __launch_bounds__(64) void k_scl_big(SclParams P)
                 R *out = lowA + p * LOW + h;
                 uint32_t wv = bl0 >> h;  // t < 5: bit 2^t + e of the register word
                 if (gstep && t == 5) wv = blw[ptr_get<LOGL>(ptrB, 5) * WL + 1];
-                if (t == Cfg::TL) {
+                if (t == TL) {
                     const R *src = hiA + (size_t)ss * N + 2 * h;
-                    constexpr int U = (32 / S) < 8 ? (32 / S) : 8;   // loads in flight per lane
+                    constexpr int PER = (1 << TL) / S;                // elements per lane
+                    constexpr int U = PER < 1 ? 1 : (PER < 8 ? PER : 8);   // loads in flight per lane
                     for (int e0 = pos; e0 < h; e0 += S * U) {
                         R a[U], b[U];
 #pragma unroll
@@ -164,23 +232,29 @@ __global__ __launch_bounds__(64) void k_scl_big(SclParams P)
         };
 
         for (int j = 0; j < N; ++j) {
+            // per-leaf constants, one coalesced vector load per 64 leaves (a scalar load per leaf would put its whole
+            // latency in front of the next LDS wait: both count on lgkmcnt)
+            if ((j & 63) == 0) {
+                ctv = P.crc_tab ? P.crc_tab[j + lane] : 0u;      // CRC remainder of leaf j + lane
+                fw = P.frozen[(j >> 5) + (lane & 1)];            // frozen masks of leaves j..j+31 / j+32..j+63
+            }
             // ================= LLR of leaf j for every active path =================
             int tf = n - 1;
             if (j > 0) {
                 const int d = __builtin_ctz((unsigned)j);
-                if (d > Cfg::TL) bulk(d, true);
+                if (d > TL) bulk(d, true);
                 else low(d, true);
                 tf = d - 1;
             }
             for (int t = tf; t >= 0; --t) {
-                if (t > Cfg::TL) bulk(t, false);
+                if (t > TL) bulk(t, false);
                 else low(t, false);
             }
             const R lam = (p < act) ? lowA[p * LOW + 1] : R(0);
+            BIG_STAMP(3);
 
             // ================= decision =================
-            if ((j & 31) == 0) fw = P.frozen[j >> 5];
-            const bool frozen = (fw >> (j & 31)) & 1;
+            const bool frozen = (__builtin_amdgcn_readlane(fw, (j >> 5) & 1) >> (j & 31)) & 1;
             int bit = 0;
             if (frozen) {
                 if (p < act) PM += lut.tabv(lam) + negmax(lam);  // PHI(.,0), SCL_1024.c:601-604, :662-665
@@ -229,17 +303,16 @@ __global__ __launch_bounds__(64) void k_scl_big(SclParams P)
                 const int nboth = __popcll(m_both);
                 bool refilled = false;
                 if (nboth) {
-                    if (s0 && s1 && pos == 0) tbl[__popcll(m_both & below)] = p;
-                    if (pos == 0) {
+                    if (s0 && s1 && pos == 0) {   // the m-th both-survivor leaves its state in row m
                         State me;
                         me.ptrA = ptrA; me.ptrB = ptrB; me.c1 = c1; me.crc = crc; me.bl0 = bl0;
-                        st[p] = me;
+                        st[__popcll(m_both & below)] = me;
                     }
                     __asm__ volatile("" ::: "memory");
                     const int rank_dead = __popcll(m_dead & below);
                     refilled = !s0 && !s1 && rank_dead < nboth;
                     if (refilled) {
-                        const State src = st[tbl[rank_dead]];
+                        const State src = st[rank_dead];
                         ptrA = src.ptrA; ptrB = src.ptrB; crc = src.crc; bl0 = src.bl0;
                         PM = src.c1;
                         bit = 1;
@@ -260,8 +333,9 @@ __global__ __launch_bounds__(64) void k_scl_big(SclParams P)
                 __asm__ volatile("" ::: "memory");
             }
 
+            BIG_STAMP(frozen ? 4 : 5);
             // ================= partial sums (updateBit, SCL_1024.c:424-448) =================
-            if (P.crc_tab && bit) crc ^= P.crc_tab[j];
+            if (bit) crc ^= __builtin_amdgcn_readlane(ctv, j & 63);
             cur0 = (uint32_t)bit;
             int t = 0;
             while (t < n && ((j >> t) & 1)) {
@@ -279,7 +353,7 @@ __global__ __launch_bounds__(64) void k_scl_big(SclParams P)
                     }
                     if (p < act) {
                         const int bs = ptr_get<LOGL>(ptrB, t);
-                        if (t < 8) {          // cur_t, bl_t, cur_{t+1} (<= 8 words) all in LDS
+                        if (t <= TB) {        // cur_t, bl_t, cur_{t+1} (<= WLU words) all in LDS
                             for (int w = pos; w < nw; w += S) {
                                 const uint32_t c = curw[p * WL + w];
                                 const uint32_t l = blw[bs * WL + nw + w];
@@ -288,15 +362,15 @@ __global__ __launch_bounds__(64) void k_scl_big(SclParams P)
                             }
                         } else {              // result goes to the scratch slice
                             for (int w = pos; w < nw; w += S) {
-                                const uint32_t c = (t == 8) ? curw[p * WL + w] : ld_bypass(gcur + (size_t)p * NW + w);
+                                const uint32_t c = (t == TB + 1) ? curw[p * WL + w] : ld_bypass(gcur + (size_t)p * NW + w);
                                 const uint32_t l = ld_bypass(gbl + (size_t)bs * NW + nw + w);
                                 gcur[(size_t)p * NW + w] = l ^ c;
                                 gcur[(size_t)p * NW + w + nw] = c;
                             }
                         }
                     }
-                    if (t < 8) __asm__ volatile("" ::: "memory");
-                    else __syncthreads();
+                    if (t <= TB) __asm__ volatile("" ::: "memory");
+                    else wave_sync();
                 }
                 ++t;
             }
@@ -310,18 +384,19 @@ __global__ __launch_bounds__(64) void k_scl_big(SclParams P)
                     if (p < act) {
                         if (t == 5) {
                             if (pos == 0) blw[p * WL + 1] = cur0;
-                        } else if (t < 8) {
+                        } else if (t <= TB) {
                             for (int w = pos; w < nw; w += S) blw[p * WL + nw + w] = curw[p * WL + w];
                         } else {
                             for (int w = pos; w < nw; w += S)
-                                gbl[(size_t)p * NW + nw + w] = (t == 8) ? curw[p * WL + w] : ld_bypass(gcur + (size_t)p * NW + w);
+                                gbl[(size_t)p * NW + nw + w] = (t == TB + 1) ? curw[p * WL + w] : ld_bypass(gcur + (size_t)p * NW + w);
                         }
                         ptrB = ptr_set<LOGL>(ptrB, t, p);
                     }
-                    if (t < 8) __asm__ volatile("" ::: "memory");
-                    else __syncthreads();
+                    if (t <= TB) __asm__ volatile("" ::: "memory");
+                    else wave_sync();
                 }
             }
+            BIG_STAMP(6);
         }
 
         // ================= choose the path (SCL_1024.c:667-674; CASCL_1024_L8.c:725-755) =================
@@ -338,10 +413,10 @@ __global__ __launch_bounds__(64) void k_scl_big(SclParams P)
             }
         }
         if (any) fl |= 0x2u;
-        // x_hat of the chosen path: root partial sums (scratch slice, n >= 9); u_hat = x_hat * F^{(x)n} in LDS
-        uint32_t *xw = reinterpret_cast<uint32_t *>(lowA);
+        // x_hat of the chosen path: root partial sums (scratch slice); u_hat = x_hat * F^{(x)n}, in place
+        uint32_t *xw = gcur + (size_t)best * NW;
         for (int w = lane; w < NW; w += 64) {
-            uint32_t x = ld_bypass(gcur + (size_t)best * NW + w);
+            uint32_t x = ld_bypass(xw + w);
             x ^= (x >> 1) & 0x55555555u;
             x ^= (x >> 2) & 0x33333333u;
             x ^= (x >> 4) & 0x0F0F0F0Fu;
@@ -349,20 +424,25 @@ __global__ __launch_bounds__(64) void k_scl_big(SclParams P)
             x ^= (x >> 16) & 0x0000FFFFu;
             xw[w] = x;
         }
-        __syncthreads();
+        wave_sync();
         for (int s = 5; s < n; ++s) {
             const int hw = 1 << (s - 5);
             for (int w = lane; w < NW; w += 64)
-                if (!(w & hw)) xw[w] ^= xw[w + hw];
-            __syncthreads();
+                if (!(w & hw)) xw[w] = ld_bypass(xw + w) ^ ld_bypass(xw + w + hw);
+            wave_sync();
         }
-        for (int w = lane; w < NW; w += 64) P.out_bits[(size_t)frame * NW + w] = xw[w];
+        for (int w = lane; w < NW; w += 64) P.out_bits[(size_t)frame * NW + w] = ld_bypass(xw + w);
         if (lane == 0) {
             if (P.pm) P.pm[frame] = (double)best_pm;
             if (P.flags) P.flags[frame] = fl;
         }
-        __syncthreads();
+        wave_sync();
+        BIG_STAMP(7);
     }
+#ifdef POLAR_STAMPS
+    if (lane == 0 && P.dbg)
+        for (int i = 0; i < 8; ++i) atomicAdd(&P.dbg[i], tsec[i]);
+#endif
 }
 
 }  // namespace polar

@@ -25,7 +25,7 @@ CONFIGS = [
     ("CASCL_1024_L8", lambda: pa.CASCL(1024, 512, L=8, dtype=dt), 1024, 1 << 17),
     ("CASCL_128_L8", lambda: pa.CASCL(128, 64, L=8, crc_taps=pa.CRC6_TAPS, dtype=dt), 128, 1 << 18),
     ("SCL_1024_L32", lambda: pa.SCLdecode(1024, 512, L=32, dtype=dt), 1024, 1 << 14),
-    ("CASCL_4096_L32", lambda: pa.CASCL(4096, 2048, L=32, dtype=dt), 4096, 1 << 13),
+    ("CASCL_4096_L32", lambda: pa.CASCL(4096, 2048, L=32, dtype=dt), 4096, 1 << 15),
 ]
 for name, mk, N, B in CONFIGS:
     if args.only and args.only not in name:
