@@ -48,13 +48,17 @@ struct BigCfg {
     static constexpr size_t off_blw = align16(sizeof(R) * (size_t)L * LOW);
     static constexpr size_t off_cur = off_blw + sizeof(uint32_t) * (size_t)L * WL;
     static constexpr size_t off_cand = align16(off_cur + sizeof(uint32_t) * (size_t)L * WL);
-    static constexpr size_t off_tbl = off_cand + sizeof(R) * 2 * L;
-    static constexpr size_t off_st = align16(off_tbl + sizeof(int) * L);
+    static constexpr size_t off_tbl = align16(off_cand + sizeof(R) * 2 * L);   // int[2L]: leader list / 32-bit metric keys
+    static constexpr size_t off_st = align16(off_tbl + sizeof(int) * 2 * L);
     static constexpr size_t wave_bytes = align16(off_st + sizeof(State) * L);
     static constexpr size_t lds_bytes = wave_bytes * WAVES + Lut<R>::bytes;
     // scratch per wave, in bytes: chg[N] + hiA[L][N] reals, then gbl[L][N/32] + gcur[L][N/32] words
     static constexpr size_t scratch_bytes(int N) { return sizeof(R) * (size_t)(L + 1) * N + 2 * sizeof(uint32_t) * (size_t)L * (N / 32); }
 };
+
+__device__ __forceinline__ int metric_key_i(double x) { return __double2hiint(x); }
+__device__ __forceinline__ int metric_key_i(float x) { return __float_as_int(x); }
+typedef int i4 __attribute__((ext_vector_type(4)));
 
 // everything a wave wrote (LDS and scratch) is visible to its own later loads; no other wave ever reads it
 __device__ __forceinline__ void wave_sync() { __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
@@ -195,8 +199,9 @@ __global__ __launch_bounds__(256) void k_scl_big(SclParams P)
             BIG_STAMP((t >= 6) ? 1 : 2);
         };
         // ---- level t <= TL from level t+1 by the path's own lanes ----
-        auto low = [&](int t, bool gstep) {
-            const int h = 1 << t;
+        auto low_c = [&](auto TC, auto GC) {
+            constexpr int t = decltype(TC)::value, h = 1 << t;
+            constexpr bool gstep = decltype(GC)::value;
             if (p < act) {
                 const int ss = ptr_get<LOGL>(ptrA, t + 1);
                 R *out = lowA + p * LOW + h;
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256) void k_scl_big(SclParams P)
                 if (gstep && t == 5) wv = blw[ptr_get<LOGL>(ptrB, 5) * WL + 1];
                 if (t == TL) {
                     const R *src = hiA + (size_t)ss * N + 2 * h;
-                    constexpr int PER = (1 << TL) / S;                // elements per lane
+                    constexpr int PER = h / S;                             // elements per lane
                     constexpr int U = PER < 1 ? 1 : (PER < 8 ? PER : 8);   // loads in flight per lane
                     for (int e0 = pos; e0 < h; e0 += S * U) {
                         R a[U], b[U];
@@ -221,14 +226,29 @@ __global__ __launch_bounds__(256) void k_scl_big(SclParams P)
                     }
                 } else {
                     const R *src = lowA + ss * LOW + 2 * h;
-                    for (int e = pos; e < h; e += S) {
-                        const R a = src[e], b = src[e + h];
-                        out[e] = gstep ? gfun<R>(a, b, (wv >> e) & 1) : chk_lut1<R>(a, b, lut);
+                    constexpr int PER = (h + S - 1) / S;
+                    if (h >= S || pos < h) {
+#pragma unroll
+                        for (int k = 0; k < PER; ++k) {
+                            const int e = pos + k * S;
+                            const R a = src[e], b = src[e + h];
+                            out[e] = gstep ? gfun<R>(a, b, (wv >> e) & 1) : chk_lut1<R>(a, b, lut);
+                        }
                     }
                 }
                 ptrA = ptr_set<LOGL>(ptrA, t, p);
             }
             __asm__ volatile("" ::: "memory");  // LDS executes one wave's operations in order
+        };
+        auto low = [&](int t, bool gstep) {
+            using std::integral_constant;
+#define POLAR_LOW_CASE(T) \
+    case T: if constexpr (T <= TL) { if (gstep) low_c(integral_constant<int, T>{}, integral_constant<bool, true>{}); \
+                                     else low_c(integral_constant<int, T>{}, integral_constant<bool, false>{}); } break;
+            switch (t) {
+                POLAR_LOW_CASE(0) POLAR_LOW_CASE(1) POLAR_LOW_CASE(2) POLAR_LOW_CASE(3) POLAR_LOW_CASE(4) POLAR_LOW_CASE(5)
+            }
+#undef POLAR_LOW_CASE
         };
 
         for (int j = 0; j < N; ++j) {
@@ -282,19 +302,41 @@ __global__ __launch_bounds__(256) void k_scl_big(SclParams P)
                 const R c0 = PM + (tt + negmax(lam));
                 const R c1 = PM + (tt + posmax(lam));
                 const R mine = (pos == 0) ? c0 : c1;
-                if (pos < 2) cand[2 * p + pos] = mine;
+                // First on 32-bit keys (the bits of a float, the high word of a double: monotone for metrics >= 0):
+                // t = key_m - key_own - 1 is negative iff key_m <= key_own, and one v_alignbit shifts that sign bit
+                // into a 32-candidate accumulator.  If exactly L candidates come out with count <= L they are the
+                // L smallest for the full values too; otherwise two keys tie at the boundary (or two metrics are
+                // equal) and the count is redone on the full values.
+                const int kown1 = metric_key_i(mine) + 1;
+                if (pos < 2) tbl[2 * p + pos] = kown1 - 1;
                 __asm__ volatile("" ::: "memory");
-                // strict "< med" with med = (L+1)-th smallest  <=>  #{m : c_m <= c} <= L
-                int cnt = 0;
-#pragma unroll 8
-                for (int m = 0; m < 2 * L; m += 2) {
-                    const R v0 = cand[m], v1 = cand[m + 1];
-                    cnt += (v0 <= mine);
-                    cnt += (v1 <= mine);
+                uint32_t acc0 = 0, acc1 = 0;
+#pragma unroll
+                for (int m = 0; m < 2 * L; m += 4) {
+                    const i4 k = *reinterpret_cast<const i4 *>(tbl + m);
+                    uint32_t &acc = (m < 32) ? acc0 : acc1;
+                    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)(k.x - kown1), 31);
+                    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)(k.y - kown1), 31);
+                    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)(k.z - kown1), 31);
+                    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)(k.w - kown1), 31);
                 }
-                const bool surv = cnt <= L;
-                const uint64_t m_s0 = __ballot(pos == 0 && surv);
-                const uint64_t m_s1 = __ballot(pos == 1 && surv) >> 1;   // aligned to the lead lanes
+                int cnt = __popc(acc0) + __popc(acc1);
+                uint64_t m_s0 = __ballot(pos == 0 && cnt <= L);
+                uint64_t m_s1 = __ballot(pos == 1 && cnt <= L) >> 1;   // aligned to the lead lanes
+                if (__popcll(m_s0) + __popcll(m_s1) < L) {
+                    // strict "< med" with med = (L+1)-th smallest  <=>  #{m : c_m <= c} <= L
+                    if (pos < 2) cand[2 * p + pos] = mine;
+                    __asm__ volatile("" ::: "memory");
+                    cnt = 0;
+#pragma unroll 8
+                    for (int m = 0; m < 2 * L; m += 2) {
+                        const R v0 = cand[m], v1 = cand[m + 1];
+                        cnt += (v0 <= mine);
+                        cnt += (v1 <= mine);
+                    }
+                    m_s0 = __ballot(pos == 0 && cnt <= L);
+                    m_s1 = __ballot(pos == 1 && cnt <= L) >> 1;
+                }
                 const uint64_t m_both = m_s0 & m_s1;
                 const uint64_t m_dead = __ballot(pos == 0) & ~(m_s0 | m_s1);
                 if (__popcll(m_s0) + __popcll(m_s1) < L) fl |= 0x1u;  // median tie ("Oops!", :621-622)
