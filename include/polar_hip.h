@@ -65,6 +65,12 @@ typedef struct polar_cfg {
                               NULL -> built from the 5G sequence like the reference does.                 */
     int dtype;             /* POLAR_F64 | POLAR_F32                                                      */
     int device;            /* HIP device ordinal                                                         */
+    int crc_systematic;    /* 0: the CRC word is v(D) g(D) (CASCL_1024_L8.c:251-266).  1: CASCL_1024_sys.c:
+                              systematic cyclic encoding, w[0..r) = D^r v(D) mod g, w[r..K+r) = v (:776-789), and
+                              the error counters look at the K payload bits only (:820-821).  The decoder is the
+                              same: that program's bit-reversed graph fed with y[bRev[j]] makes the decisions of
+                              the natural-order graph fed with y.  Used by polar_generate_device,
+                              polar_count_errors_device and polar_fer_batch; ignored without a CRC.            */
 } polar_cfg;
 
 int polar_create(const polar_cfg *cfg, polar_ctx **out);

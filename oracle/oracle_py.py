@@ -34,7 +34,8 @@ def q_for(N):
 class _Code(C.Structure):
     _fields_ = [("N", C.c_int), ("n", C.c_int), ("K", C.c_int), ("r", C.c_int), ("A", C.c_int),
                 ("ntaps", C.c_int), ("taps", C.c_int * 32),
-                ("info_order", C.POINTER(C.c_int)), ("frozen", C.POINTER(C.c_ubyte))]
+                ("info_order", C.POINTER(C.c_int)), ("frozen", C.POINTER(C.c_ubyte)),
+                ("systematic", C.c_int)]
 
 
 class _Sim(C.Structure):
@@ -55,6 +56,7 @@ def lib():
         L.po_code_create.restype = C.POINTER(_Code)
         L.po_code_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
         L.po_code_destroy.argtypes = [C.POINTER(_Code)]
+        L.po_code_set_systematic.argtypes = [C.POINTER(_Code), C.c_int]
         dp = C.POINTER(C.c_double)
         fp = C.POINTER(C.c_float)
         ip = C.POINTER(C.c_int)
@@ -89,8 +91,9 @@ def _dp(a):
 class Code:
     """N, K, CRC taps -> frozen set in 5G reliability order (CASCL_1024_L8.c:209-217)."""
 
-    def __init__(self, N, K, crc_taps=None, Q=None):
+    def __init__(self, N, K, crc_taps=None, Q=None, systematic=False):
         self.N, self.K = N, K
+        self.systematic = bool(systematic)
         self.taps = list(crc_taps) if crc_taps else []
         self.r = max(self.taps) if self.taps else 0
         q = np.asarray(Q if Q is not None else q_for(N), dtype=np.int32)
@@ -98,6 +101,8 @@ class Code:
         self._h = lib().po_code_create(N, K, self.r, _ip(t), len(self.taps), _ip(q))
         if not self._h:
             raise ValueError("bad code parameters")
+        if systematic:
+            lib().po_code_set_systematic(self._h, 1)
         self.A = K + self.r
         self.n = int(np.log2(N))
         self.info_order = np.array([self._h.contents.info_order[i] for i in range(self.A)], dtype=np.int32)
@@ -205,7 +210,10 @@ REF_PROGRAMS = {
     "SCL_1024": (1024, 512, None, "SCL", 8),
     "CASCL_128": (128, 64, CRC6_TAPS, "CASCL", 8),
     "CASCL_1024_L8": (1024, 512, CRC24C_TAPS, "CASCL", 8),
+    # systematic CRC, decoder on the bit-reversed graph (same decisions as the natural-order decoder)
+    "CASCL_1024_sys": (1024, 512, CRC24C_TAPS, "CASCL", 8),
 }
+SYSTEMATIC_PROGRAMS = ("CASCL_1024_sys",)
 
 
 def ref_available(name):

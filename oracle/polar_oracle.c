@@ -58,10 +58,31 @@ void po_crc_encode(const po_code *c, const int *v, int *w)
         for (int i = 0; i < c->K; i++) w[i] = v[i];
         return;
     }
+    if (c->systematic) {
+        /* CASCL_1024_sys.c:776-789: redundant part = sum of the rows Gc[i] = D^(r+i) mod g of the set bits,
+         * then the payload itself.  Row i is obtained here by long division of D^(r+i), the way CRcheck
+         * divides (:1100-1125); tests/golden/make_golden.py compares every row with the program's literal. */
+        const int r = c->r;
+        int *row = (int *)malloc(sizeof(int) * (size_t)c->A);
+        for (int i = 0; i < c->K; i++) {
+            if (v[i] != 1) continue;
+            for (int j = 0; j < c->A; j++) row[j] = 0;
+            row[r + i] = 1;
+            for (int j = r + i; j >= r; j--)
+                if (row[j] == 1)
+                    for (int t = 0; t < c->ntaps; t++) row[j - r + c->taps[t]] ^= 1;
+            for (int j = 0; j < r; j++) w[j] ^= row[j];
+        }
+        free(row);
+        for (int i = r; i < c->A; i++) w[i] = v[i - r];
+        return;
+    }
     for (int i = 0; i < c->K; i++)
         if (v[i] == 1)
             for (int t = 0; t < c->ntaps; t++) w[i + c->taps[t]] ^= 1;
 }
+
+void po_code_set_systematic(po_code *c, int on) { c->systematic = (on && c->r > 0) ? 1 : 0; }
 
 /* long division, pass iff remainder 0 (CASCL_1024_L8.c:569-598; CASCL_128.c:518-536) */
 int po_crc_check(const po_code *c, const int *w)
@@ -209,7 +230,7 @@ void po_sim_frame(po_sim *s, const po_code *c, double sigma, int *u, double *y)
 int po_count_bit_errors(const po_code *c, const int *u, const int *u_hat)
 {
     int e = 0;
-    for (int i = 0; i < c->A; i++)
+    for (int i = c->systematic ? c->r : 0; i < c->A; i++) /* CASCL_1024_sys.c:820-821: the K true info bits */
         if (u[c->info_order[i]] != u_hat[c->info_order[i]]) e++;
     return e;
 }

@@ -37,12 +37,18 @@ typedef struct po_code {
     int taps[PO_MAX_TAPS];
     int *info_order;   /* I[i], i < A: reliability order, I[i] = Q[N-A+i]        */
     unsigned char *frozen; /* [N] 1 = frozen                                     */
+    int systematic;    /* 0: w = v g (CASCL_1024_L8.c:251-266); 1: systematic cyclic encoding,
+                          w[0..r) = D^r v(D) mod g, w[r..A) = v (CASCL_1024_sys.c:776-789) */
 } po_code;
 
 /* Code construction (CASCL_1024_L8.c:209-217; SCL_1024.c:198-206).  Q = ascending-reliability
  * sequence restricted to < N (length N).  taps may be NULL when r == 0. */
 po_code *po_code_create(int N, int K, int r, const int *taps, int ntaps, const int *Q);
 void po_code_destroy(po_code *c);
+/* CASCL_1024_sys.c: systematic CRC encoding and the K-true-info-bit error metric (:820-821).  The decoder
+ * itself is unchanged: that program's bit-reversed graph with y[bRev[j]] on channel row j is the natural graph
+ * under the row relabelling j -> bRev[j] at every stage (:925-945, :1156-1172). */
+void po_code_set_systematic(po_code *c, int on);
 
 /* 2*y/std/std (SCL_1024.c:576) */
 void po_llr_from_y(const double *y, double sigma, double *llr, int N);

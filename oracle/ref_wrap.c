@@ -8,6 +8,7 @@
  *   -DREF_SRC="\"/root/reference/CASCL_1024_L8.c\""   the translation unit to wrap
  *   -DREF_DECODE=CASCL                                  its decode entry point
  *   -DREF_KIND=3                                        0 SC, 1 BP, 2 SCL, 3 CASCL
+ *   -DREF_BITREV                                        the program decodes on the bit-reversed graph (CASCL_1024_sys.c)
  *
  * What is restated here (because the reference keeps it inline in main(), SCL_1024.c:159-217) is
  * only the graph/frozen-set SET-UP, done with the reference's own connectBCB() and Q table.
@@ -89,6 +90,15 @@ int ref_init(void)
         V[REF_LOG][b]->cU = NULL;
         V[REF_LOG][b]->cL = NULL;
     }
+#ifdef REF_BITREV
+    /* CASCL_1024_sys.c:726-735 builds bRev[] inline in main(): index with its REF_LOG bits reversed */
+    for (a = 0; a < REF_BLOCK; a++) {
+        int rev = 0;
+        for (b = 0; b < REF_LOG; b++)
+            if ((a >> b) & 1) rev |= 1 << (REF_LOG - 1 - b);
+        bRev[a] = rev;
+    }
+#endif
     for (a = 0; a < REF_BLOCK; a++) inI[a] = 0;
     for (a = 0; a < REF_INFO + REF_CRC; a++) {
         I[a] = Q[REF_BLOCK - (REF_INFO + REF_CRC) + a];

@@ -30,7 +30,8 @@ class PolarError(RuntimeError):
 class _Cfg(C.Structure):
     _fields_ = [("N", C.c_int), ("K", C.c_int), ("crc_r", C.c_int), ("crc_taps", C.POINTER(C.c_int)),
                 ("n_taps", C.c_int), ("L", C.c_int), ("algo", C.c_int), ("bp_iters", C.c_int),
-                ("info_order", C.POINTER(C.c_int)), ("dtype", C.c_int), ("device", C.c_int)]
+                ("info_order", C.POINTER(C.c_int)), ("dtype", C.c_int), ("device", C.c_int),
+                ("crc_systematic", C.c_int)]
 
 
 def lib_path():
@@ -105,7 +106,8 @@ def _ptr(a, ty):
 class Decoder:
     """One polar_ctx: a (N, K, CRC, L, algo, dtype) configuration bound to one GPU."""
 
-    def __init__(self, N, K, algo, L=1, crc_taps=None, bp_iters=100, dtype=F64, device=0, info_order=None):
+    def __init__(self, N, K, algo, L=1, crc_taps=None, bp_iters=100, dtype=F64, device=0, info_order=None,
+                 systematic=False):
         self._h = C.c_void_p()
         self._lib = load_library()
         self.N, self.K, self.algo, self.dtype, self.device = N, K, algo, dtype, device
@@ -116,6 +118,8 @@ class Decoder:
         cfg.crc_taps = _ptr(taps, C.c_int)
         cfg.n_taps = len(taps) if crc_taps else 0
         cfg.L, cfg.algo, cfg.bp_iters, cfg.dtype, cfg.device = L, algo, bp_iters, dtype, device
+        cfg.crc_systematic = 1 if systematic else 0   # CASCL_1024_sys.c: encoder and error metric only
+        self.systematic = bool(systematic)
         io = None
         if info_order is not None:
             io = np.ascontiguousarray(info_order, dtype=np.int32)
@@ -274,7 +278,8 @@ def SCLdecode(N, K, L=8, **kw):
 
 
 def CASCL(N, K, L=8, crc_taps=CRC24C_TAPS, **kw):
-    """CASCL_1024_L8.c:601 -- ``CASCL(y, u_hat)``; r and g(D) are CASCL_1024_L8.c:2-4, :19."""
+    """CASCL_1024_L8.c:601 -- ``CASCL(y, u_hat)``; r and g(D) are CASCL_1024_L8.c:2-4, :19.
+    ``systematic=True`` is CASCL_1024_sys.c: same decoder, systematic CRC in the generator, K-bit error metric."""
     return Decoder(N, K, ALGO_CASCL, L=L, crc_taps=crc_taps, **kw)
 
 

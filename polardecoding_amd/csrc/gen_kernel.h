@@ -20,6 +20,7 @@ struct GenParams {
     uint32_t crc_mask;       // bit t set <=> D^t in g(D), t < 32 (taps 0..r); 1 when no CRC
     uint32_t crc_top;        // tap r when r == 32 handled via crc_r
     int crc_r;
+    const uint32_t *gc_rows; // systematic CRC (CASCL_1024_sys.c:48-561): row k = D^(r+k) mod g as an r-bit mask; else null
     int N, n, K, A, B;
     int out_is_f32, out_is_y;
 };
@@ -73,6 +74,19 @@ __global__ __launch_bounds__(256) void k_generate(GenParams P)
         for (int j = lane; j < N; j += 64) ub[j] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (P.gc_rows) {
+            // systematic CRC (CASCL_1024_sys.c:776-789): redundant part = sum of the generator rows of the set
+            // payload bits, then the payload itself; placement u[I[i]] = w[i]
+            uint32_t par = 0;
+            for (int k = lane; k < P.K; k += 64)
+                if ((vw[k >> 5] >> (k & 31)) & 1u) par ^= P.gc_rows[k];
+            for (int o = 32; o > 0; o >>= 1) par ^= __shfl_xor(par, o);
+            for (int i = lane; i < P.A; i += 64) {
+                const int q = i - P.crc_r;
+                const uint32_t bit = (q < 0) ? ((par >> i) & 1u) : ((vw[q >> 5] >> (q & 31)) & 1u);
+                ub[P.info_order[i]] = (unsigned char)bit;
+            }
+        } else {
         // CRC multiply w(D) = v(D) g(D) (CASCL_1024_L8.c:251-266) and placement u[I[i]] = w[i] (:270-272)
         for (int i = lane; i < P.A; i += 64) {
             uint32_t bit = 0;
@@ -82,6 +96,7 @@ __global__ __launch_bounds__(256) void k_generate(GenParams P)
                 if (tap && q >= 0 && q < P.K) bit ^= (vw[q >> 5] >> (q & 31)) & 1u;
             }
             ub[P.info_order[i]] = (unsigned char)bit;
+        }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -43,6 +43,7 @@ struct polar_ctx {
     uint32_t *d_frozen = nullptr;         // [NW] bit = frozen
     uint32_t *d_info = nullptr;           // [NW] bit = unfrozen
     uint32_t *d_crc_tab = nullptr;        // [N] or null
+    uint32_t *d_gc_rows = nullptr;        // [K] systematic CRC generator rows (D^(r+k) mod g), or null
     uint32_t *d_frozen_override = nullptr;
     int *d_info_order = nullptr;          // [A] for the device-side generator
     hipStream_t stream = nullptr;
@@ -505,6 +506,27 @@ int polar_create(const polar_cfg *cfg, polar_ctx **out)
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return cleanup(POLAR_EDEVICE);
     std::vector<uint32_t> fw = pack_mask(c->frozen.data(), N, false);
     std::vector<uint32_t> iw = pack_mask(c->frozen.data(), N, true);
+    c->cfg.crc_systematic = (cfg->crc_systematic && r > 0) ? 1 : 0;
+    if (c->cfg.crc_systematic) {
+        // error metric over the K payload positions I[r..K+r) only (CASCL_1024_sys.c:820-821)
+        std::fill(iw.begin(), iw.end(), 0u);
+        for (int i = r; i < c->A; ++i) iw[c->info_order[i] >> 5] |= 1u << (c->info_order[i] & 31);
+        // generator rows D^(r+k) mod g (the literal Gc[K][r] of CASCL_1024_sys.c:48-561), bit j = coefficient of D^j
+        std::vector<uint32_t> rows((size_t)cfg->K);
+        uint64_t glow = 0;
+        for (int t : c->taps)
+            if (t < r) glow |= 1ull << t;
+        const uint64_t top = 1ull << r;
+        uint64_t rem = glow;   // D^r mod g
+        for (int k = 0; k < cfg->K; ++k) {
+            rows[(size_t)k] = (uint32_t)rem;
+            rem <<= 1;
+            if (rem & top) rem = (rem ^ top) ^ glow;
+        }
+        if (hipMalloc(&c->d_gc_rows, rows.size() * 4) != hipSuccess) return cleanup(POLAR_ENOMEM);
+        if (hipMemcpy(c->d_gc_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup(POLAR_EDEVICE);
+    }
     if (hipMalloc(&c->d_frozen, c->NW * 4) != hipSuccess || hipMalloc(&c->d_info, c->NW * 4) != hipSuccess)
         return cleanup(POLAR_ENOMEM);
     if (hipMemcpy(c->d_frozen, fw.data(), c->NW * 4, hipMemcpyHostToDevice) != hipSuccess ||
@@ -556,6 +578,7 @@ void polar_destroy(polar_ctx *c)
     if (c->d_crc_tab) (void)hipFree(c->d_crc_tab);
     if (c->d_frozen_override) (void)hipFree(c->d_frozen_override);
     if (c->d_info_order) (void)hipFree(c->d_info_order);
+    if (c->d_gc_rows) (void)hipFree(c->d_gc_rows);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -694,6 +717,7 @@ int polar_generate_device(polar_ctx *c, unsigned long long seed, unsigned long l
     P.seed = seed; P.first_frame = first_frame;
     P.sigma = std::pow(10.0, snr_db / -20.0);  // SCL_1024.c:226
     P.crc_r = g.crc_r; P.crc_mask = 0; P.crc_top = 0;
+    P.gc_rows = c->d_gc_rows;
     if (g.crc_r == 0) P.crc_mask = 1u;
     for (int t : c->taps) {
         if (t < 32) P.crc_mask |= 1u << t;

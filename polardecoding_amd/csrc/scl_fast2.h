@@ -387,14 +387,18 @@ struct Fast2Dec {
         const unsigned char *kb = reinterpret_cast<const unsigned char *>(keys) - 64 * c;  // wave base of keys[2][16]
         const uint32_t own = *reinterpret_cast<const uint32_t *>(kb + own_addr);
         const uint32_t oth = *reinterpret_cast<const uint32_t *>(kb + oth_addr);
-        uint32_t cnt = (oth <= own) ? 1u : 0u;
-        cnt += ((uint32_t)dpp_i<0x121>((int)oth) <= own) ? 1u : 0u;
-        cnt += ((uint32_t)dpp_i<0x122>((int)oth) <= own) ? 1u : 0u;
-        cnt += ((uint32_t)dpp_i<0x123>((int)oth) <= own) ? 1u : 0u;
-        cnt += ((uint32_t)dpp_i<0x124>((int)oth) <= own) ? 1u : 0u;
-        cnt += ((uint32_t)dpp_i<0x125>((int)oth) <= own) ? 1u : 0u;
-        cnt += ((uint32_t)dpp_i<0x126>((int)oth) <= own) ? 1u : 0u;
-        cnt += ((uint32_t)dpp_i<0x127>((int)oth) <= own) ? 1u : 0u;
+        // key_m - key_own - 1 is negative iff key_m <= key_own (keys < 2^31); one v_alignbit shifts that sign
+        // bit into the accumulator: two full-rate instructions per comparison instead of cmp + addc
+        const uint32_t own1 = own + 1u;
+        uint32_t acc = (oth - own1) >> 31;
+        acc = __builtin_amdgcn_alignbit(acc, (uint32_t)dpp_i<0x121>((int)oth) - own1, 31);
+        acc = __builtin_amdgcn_alignbit(acc, (uint32_t)dpp_i<0x122>((int)oth) - own1, 31);
+        acc = __builtin_amdgcn_alignbit(acc, (uint32_t)dpp_i<0x123>((int)oth) - own1, 31);
+        acc = __builtin_amdgcn_alignbit(acc, (uint32_t)dpp_i<0x124>((int)oth) - own1, 31);
+        acc = __builtin_amdgcn_alignbit(acc, (uint32_t)dpp_i<0x125>((int)oth) - own1, 31);
+        acc = __builtin_amdgcn_alignbit(acc, (uint32_t)dpp_i<0x126>((int)oth) - own1, 31);
+        acc = __builtin_amdgcn_alignbit(acc, (uint32_t)dpp_i<0x127>((int)oth) - own1, 31);
+        uint32_t cnt = __popc(acc);
         {
             auto r = __builtin_amdgcn_permlane16_swap(cnt, cnt, false, false);
             cnt = r[0] + r[1];

@@ -74,6 +74,7 @@ typedef struct {
     int N, K, r, A, ntaps;
     int taps[32];
     int *I; /* info order */
+    int sys; /* --sys: systematic CRC encoding and K-bit error metric (CASCL_1024_sys.c) */
 } code_t;
 
 static void make_frame(gen_state *g, const code_t *c, double sigma, unsigned char *u, double *y)
@@ -82,6 +83,16 @@ static void make_frame(gen_state *g, const code_t *c, double sigma, unsigned cha
     static int w[4096 + 64];
     static unsigned char x[4096];
     for (int i = 0; i < c->A; i++) w[i] = 0;
+    if (c->sys && c->r > 0) {
+        /* CASCL_1024_sys.c:776-789: w[r..A) = payload, w[0..r) = D^r v(D) mod g (sum of the generator rows) */
+        for (int i = 0; i < c->K; i++) w[c->r + i] = PN[(g->m + i) % 63];
+        static int d[4096 + 64];
+        for (int i = 0; i < c->A; i++) d[i] = (i < c->r) ? 0 : w[i];
+        for (int i = c->A - 1; i >= c->r; i--)
+            if (d[i])
+                for (int t = 0; t < c->ntaps; t++) d[i - c->r + c->taps[t]] ^= 1;
+        for (int i = 0; i < c->r; i++) w[i] = d[i];
+    } else
     for (int i = 0; i < c->K; i++)
         if (PN[(g->m + i) % 63]) {
             if (c->r == 0) w[i] ^= 1;
@@ -108,7 +119,7 @@ static const int CRC6[] = {0, 5, 6};
 
 static void usage(void)
 {
-    fprintf(stderr, "usage: polar_sim --algo sc|bp|scl|cascl --N n --K k [--L l] [--crc 24c|6] [--seed s] [--ble b]\n"
+    fprintf(stderr, "usage: polar_sim --algo sc|bp|scl|cascl --N n --K k [--L l] [--crc 24c|6] [--sys] [--seed s] [--ble b]\n"
                     "                 [--snr lo:hi:step] [--batch b] [--dtype f64|f32] [--bp-iters i] [--q file]\n");
     exit(2);
 }
@@ -116,7 +127,7 @@ static void usage(void)
 int main(int argc, char **argv)
 {
     int N = 1024, K = 512, L = 8, algo = POLAR_ALGO_CASCL, ble = 100, batch = 4096, dtype = POLAR_F64, bp_iters = 100;
-    int fast = 0;
+    int fast = 0, sys = 0;
     uint64_t seed = 1024;
     double lo = 1.0, hi = 3.0, step = 0.5;
     const char *crc = NULL, *qfile = NULL;
@@ -138,6 +149,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--bp-iters") && v) { bp_iters = atoi(v); i++; }
         else if (!strcmp(a, "--q") && v) { qfile = v; i++; }
         else if (!strcmp(a, "--fast")) { fast = 1; }
+        else if (!strcmp(a, "--sys")) { sys = 1; }
         else if (!strcmp(a, "--dtype") && v) { dtype = !strcmp(v, "f32") ? POLAR_F32 : POLAR_F64; i++; }
         else if (!strcmp(a, "--snr") && v) {
             if (sscanf(v, "%lf:%lf:%lf", &lo, &hi, &step) != 3) usage();
@@ -156,12 +168,14 @@ int main(int argc, char **argv)
         c.r = c.taps[c.ntaps - 1];
     }
     c.A = K + c.r;
+    c.sys = sys && c.r > 0;
     (void)qfile;
 
     polar_cfg cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.N = N; cfg.K = K; cfg.crc_r = c.r; cfg.crc_taps = c.r ? c.taps : NULL; cfg.n_taps = c.ntaps;
     cfg.L = L; cfg.algo = algo; cfg.bp_iters = bp_iters; cfg.info_order = NULL; cfg.dtype = dtype; cfg.device = 0;
+    cfg.crc_systematic = c.sys;
     polar_ctx *ctx = NULL;
     int rc = polar_create(&cfg, &ctx);
     if (rc) { fprintf(stderr, "polar_create: %s\n", polar_strerror(rc)); return 1; }
@@ -188,7 +202,7 @@ int main(int argc, char **argv)
                 run += (unsigned long long)batch;
             }
             printf("L = %d\tbSNR = %.2lf\terror block = %llu\trun = %llu\tBLER = %le\tBER = %le\n", L, db, blk, run,
-                   (double)blk / (double)run, (double)bits / (double)run / (double)c.A);
+                   (double)blk / (double)run, (double)bits / (double)run / (double)(c.sys ? c.K : c.A));
             fflush(stdout);
         }
         polar_destroy(ctx);
@@ -208,7 +222,7 @@ int main(int argc, char **argv)
             int f;
             for (f = 0; f < batch && errblock < ble; f++) { /* :296-305 */
                 int e = 0;
-                for (int i = 0; i < c.A; i++) {
+                for (int i = c.sys ? c.r : 0; i < c.A; i++) { /* CASCL_1024_sys.c:820-821: payload bits only */
                     const int j = c.I[i];
                     e += (u[(size_t)f * N + j] != (unsigned char)uh[(size_t)f * N + j]);
                 }
@@ -221,6 +235,9 @@ int main(int argc, char **argv)
         if (algo == POLAR_ALGO_SC || algo == POLAR_ALGO_BP) {
             printf("bSNR = %.2lf\terror block = %d\trun = %ld\tBLER = %lf\n", db, errblock, run, (double)errblock / run);
             printf("Error bit = %ld\tBER = %lf\n", errbit, (double)errbit / K / run);
+        } else if (c.sys) { /* CASCL_1024_sys.c:832-835 */
+            printf("bSNR = %.2lf\trun = %ld\tBLER = %lfe-3\t", db, run, (double)errblock / (run / 1000.0));
+            printf("Error bit = %ld\tBER = %lfe-3\n", errbit, (double)errbit / K / (run / 1000.0));
         } else {
             printf("L = %d\tbSNR = %.2lf\terror block = %d\trun = %ld\tBLER = %lfe-4\n", L, db, errblock, run,
                    (double)errblock / (run / 10000.0));

@@ -34,9 +34,13 @@ REF = "/root/reference"
 SNRS = (1.0, 2.0, 3.0)
 
 
-def make_vectors():
+def make_vectors(only=None):
     for name, (N, K, taps, algo, L) in O.REF_PROGRAMS.items():
-        code = O.Code(N, K, taps)
+        if only and name not in only:
+            continue
+        code = O.Code(N, K, taps, systematic=name in O.SYSTEMATIC_PROGRAMS)
+        if code.systematic:
+            check_systematic_rows(name, code)
         ref = O.Ref(name)
         per = 8 if N == 1024 else 32
         if algo == "BP" and N == 1024:
@@ -54,6 +58,26 @@ def make_vectors():
                             u_hat=np.array(uhs, dtype=np.uint8), pm=np.array(pms))
         nerr = sum(int((a != b).any()) for a, b in zip(us, uhs))
         print(f"{name}: {len(sig)} frames, {nerr} in error")
+
+
+def check_systematic_rows(name, code):
+    """The systematic program carries the redundant part of its generator matrix as a K x r literal
+    (CASCL_1024_sys.c:48-561).  The oracle derives the rows as D^(r+i) mod g; compare all of them with the
+    literal here, where the reference can be read (nothing of it is stored)."""
+    text = open(os.path.join(REF, name + ".c")).read()
+    body = text[text.index("Gc[K][r]"):]
+    body = body[body.index("{") + 1:body.index("};")]
+    rows = [[int(t) for t in re.findall(r"[01]", row)] for row in re.findall(r"\{([^{}]*)\}", body)]
+    assert len(rows) == code.K and all(len(r) == code.r for r in rows), (len(rows), code.K)
+    import ctypes as C
+    for i, row in enumerate(rows):
+        v = np.zeros(code.K, dtype=np.int32)
+        v[i] = 1
+        w = np.zeros(code.A, dtype=np.int32)
+        O.lib().po_crc_encode(code._h, v.ctypes.data_as(C.POINTER(C.c_int)), w.ctypes.data_as(C.POINTER(C.c_int)))
+        assert w[:code.r].tolist() == row, f"generator row {i} differs from the reference literal"
+        assert w[code.r + i] == 1 and w[code.r:].sum() == 1
+    print(f"{name}: {len(rows)} generator rows equal D^(r+i) mod g")
 
 
 def parse_log(text):
@@ -97,5 +121,6 @@ def make_published():
 
 
 if __name__ == "__main__":
-    make_vectors()
-    make_published()
+    make_vectors(sys.argv[1:] or None)   # optional: names of the programs to regenerate
+    if len(sys.argv) == 1:
+        make_published()

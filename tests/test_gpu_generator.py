@@ -54,6 +54,51 @@ def test_generator_encoder_and_crc(N, K, taps):
         assert not rem[:, :r].any()
 
 
+def test_generator_systematic_crc_and_payload_metric():
+    """crc_systematic = 1 (CASCL_1024_sys.c:776-789, :820-821): w[r..K+r) is the payload, w[0..r) the remainder that
+    makes w(D) a multiple of g(D); the error counters ignore the r parity positions."""
+    import torch
+    import polardecoding_amd as pa
+    taps = pa.CRC24C_TAPS
+    r, N, K = max(taps), 1024, 512
+    sysd = pa.CASCL(N, K, L=8, systematic=True)
+    plain = pa.CASCL(N, K, L=8)
+    B = 128
+    y = torch.empty(B, N, dtype=torch.float64, device="cuda")
+    ub = torch.empty(B, N // 32, dtype=torch.int32, device="cuda")
+    ub2 = torch.empty(B, N // 32, dtype=torch.int32, device="cuda")
+    sysd.generate_device(7, 0, 40.0, y, ub, out_is_y=True)
+    plain.generate_device(7, 0, 40.0, y, ub2, out_is_y=True)
+    sysd.synchronize(); plain.synchronize()
+    io = sysd.info_order
+    w = _unpack(ub, N)[:, io]
+    w2 = _unpack(ub2, N)[:, io]
+    # same Philox payload v in both modes: plain w2 = v g, so v is recovered by dividing; here simply re-encode
+    v = w[:, r:]
+    prod = np.zeros_like(w2)
+    for t in taps:
+        prod[:, t:t + K] ^= v
+    assert np.array_equal(prod, w2)                 # the non-systematic word of the same payload
+    rem = w.copy()
+    for i in range(rem.shape[1] - 1, r - 1, -1):
+        rows = rem[:, i] == 1
+        for t in taps:
+            rem[rows, i - r + t] ^= 1
+    assert not rem[:, :r].any()                     # systematic word is a multiple of g(D)
+    # error metric: flipping a parity position is not counted, flipping a payload position is
+    uh = ub.clone()
+    uh[:, io[0] // 32] ^= (1 << (int(io[0]) % 32)) if io[0] % 32 != 31 else -(1 << 31)
+    cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+    sysd.count_errors_device(uh, ub, cnt)
+    sysd.synchronize()
+    assert cnt.tolist() == [0, 0]
+    uh[:, io[r] // 32] ^= (1 << (int(io[r]) % 32)) if io[r] % 32 != 31 else -(1 << 31)
+    cnt.zero_()
+    sysd.count_errors_device(uh, ub, cnt)
+    sysd.synchronize()
+    assert cnt.tolist() == [B, B]
+
+
 def test_generator_depends_only_on_seed_and_frame_index():
     import torch
     import polardecoding_amd as pa

@@ -50,3 +50,15 @@ def test_published_run_counts(key, seed, L, n, args):
     exp, ble = published(key, seed, L, n)
     got, text = run_sim(args + ["--seed", str(seed), "--ble", str(ble), "--batch", "512"])
     assert got == exp, text
+
+
+def test_systematic_program_run_counts(oracle):
+    """CASCL_1024_sys.c (systematic CRC, K-bit error metric) has no published log; its run counts come from the
+    oracle, whose decoder matches the compiled program on the fixtures and whose generator rows were compared with
+    the program's literal (tests/golden/make_golden.py).  Same seed, same stop rule, same counts."""
+    assert os.path.exists(SIM), "polar_sim not built (run __graft_entry__.build())"
+    code = oracle.Code(1024, 512, oracle.CRC24C_TAPS, systematic=True)
+    exp, _ = oracle.run_sweep(code, "CASCL", [1.0, 1.5], 12, 4711, L=8)
+    got, text = run_sim(["--algo", "cascl", "--N", "1024", "--K", "512", "--L", "8", "--crc", "24c", "--sys",
+                         "--snr", "1.0:1.5:0.5", "--seed", "4711", "--ble", "12", "--batch", "256"])
+    assert got == exp, text

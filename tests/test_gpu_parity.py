@@ -17,6 +17,9 @@ PROGRAMS = {
     "SCL_1024": (1024, 512, "SCLdecode", {"L": 8}),
     "CASCL_128": (128, 64, "CASCL", {"L": 8, "crc_taps": (0, 5, 6)}),
     "CASCL_1024_L8": (1024, 512, "CASCL", {"L": 8}),
+    # CASCL_1024_sys.c decodes on the bit-reversed graph with y[bRev[j]] on channel row j: the same decisions as the
+    # natural-order decoder on y, which these fixtures (made by the compiled program) show frame by frame
+    "CASCL_1024_sys": (1024, 512, "CASCL", {"L": 8, "systematic": True}),
 }
 
 

@@ -5,13 +5,14 @@ import pytest
 
 from conftest import load_golden
 
-PROGRAMS = ["SC_128", "SC_1024", "BP_128", "BP_1024", "SCL_128", "SCL_1024", "CASCL_128", "CASCL_1024_L8"]
+PROGRAMS = ["SC_128", "SC_1024", "BP_128", "BP_1024", "SCL_128", "SCL_1024", "CASCL_128", "CASCL_1024_L8",
+            "CASCL_1024_sys"]  # the last one decodes on the bit-reversed graph: same decisions
 
 
 @pytest.mark.parametrize("name", PROGRAMS)
 def test_oracle_matches_golden(name, oracle):
     N, K, taps, algo, L = oracle.REF_PROGRAMS[name]
-    code = oracle.Code(N, K, taps)
+    code = oracle.Code(N, K, taps, systematic=name in oracle.SYSTEMATIC_PROGRAMS)
     g = load_golden(name)
     n = len(g["sigma"]) if N == 128 or algo != "BP" else 4
     for i in range(n):
@@ -28,7 +29,7 @@ def test_oracle_matches_compiled_reference(name, oracle):
     if not oracle.ref_available(name):
         pytest.skip("oracle/_ref not built (needs /root/reference)")
     N, K, taps, algo, L = oracle.REF_PROGRAMS[name]
-    code = oracle.Code(N, K, taps)
+    code = oracle.Code(N, K, taps, systematic=name in oracle.SYSTEMATIC_PROGRAMS)
     ref = oracle.Ref(name)
     sim = oracle.Sim(4242)
     nfr = 6 if (N == 1024 and algo != "SC") else 40
@@ -60,6 +61,32 @@ def test_golden_inputs_are_consistent(oracle):
                 for t in oracle.CRC24C_TAPS:
                     c[k - code.r + t] ^= 1
         assert not c[:code.r].any()
+
+
+def test_systematic_fixture_words_are_systematic_codewords(oracle):
+    """CASCL_1024_sys.c:776-789: w[r..K+r) is the payload itself, w[0..r) the remainder that makes w(D) a
+    multiple of g(D) (checked with the long division of CRcheck, :1100-1125)."""
+    g = load_golden("CASCL_1024_sys")
+    code = oracle.Code(1024, 512, oracle.CRC24C_TAPS, systematic=True)
+    sim = oracle.Sim(20261004 + 1024 + len("CASCL_1024_sys"))   # the fixture's seed (make_golden.py)
+    for i in range(6):
+        u_again, _ = sim.frame(code, float(g["sigma"][i]))
+        u = g["u"][i].astype(np.int32)
+        assert np.array_equal(u, u_again)
+        w = u[code.info_order]
+        c = w.copy()
+        for k in range(code.A - 1, code.r - 1, -1):
+            if c[k]:
+                for t in oracle.CRC24C_TAPS:
+                    c[k - code.r + t] ^= 1
+        assert not c[:code.r].any()
+    # the K true info bits are the only ones the error metric looks at (:820-821)
+    u = g["u"][0].astype(np.int32)
+    uh = u.copy()
+    uh[code.info_order[0]] ^= 1          # a parity position
+    assert oracle.count_bit_errors(code, u, uh) == 0
+    uh[code.info_order[code.r]] ^= 1     # the first payload position
+    assert oracle.count_bit_errors(code, u, uh) == 1
 
 
 def test_crc6_dat_semantics():
