@@ -19,6 +19,7 @@
 #include "scl_fast2.h"
 #include "scl_generic.h"
 #include "scl_big.h"
+#include "sc_lanes.h"
 
 namespace {
 
@@ -181,6 +182,36 @@ int launch_big_v(polar_ctx *c, const polar::SclParams &P)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
     return POLAR_OK;
+}
+
+// SC, one codeword per lane (sc_lanes.h)
+template <typename R, typename IN>
+int launch_sc_lanes(polar_ctx *c, const polar::SclParams &P)
+{
+    using Cfg = polar::ScLanesCfg<R>;
+    auto kern = polar::k_sc_lanes<R, IN>;
+    const size_t lds = Cfg::lds_bytes;
+    const int threads = 64 * Cfg::WAVES;
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds));
+    if (occ < 1) occ = 1;
+    const long long batches = ((long long)P.B + 63) / 64;
+    int grid = (int)std::min<long long>((batches + Cfg::WAVES - 1) / Cfg::WAVES, (long long)occ * c->num_cu);
+    if (grid < 1) grid = 1;
+    polar::SclParams Q = P;
+    int rc = ensure(c, c->scratch, Cfg::scratch_bytes(P.N) * (size_t)grid * Cfg::WAVES);
+    if (rc) return rc;
+    Q.scratch = c->scratch.p;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, Q);
+    HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
+static bool sc_lanes_ok(const polar_ctx *c, size_t B)
+{
+    return c->cfg.algo == POLAR_ALGO_SC && !c->force_generic && c->cfg.N <= 1024 && B >= 64;
 }
 
 // the LDS / scratch split that measured best per arithmetic type (profiles/README.md); POLAR_BIG_SPLIT=35|46|57 overrides
@@ -360,6 +391,10 @@ int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sig
     }
     P.dbg = s_dbg;
 #endif
+    if (sc_lanes_ok(c, B)) {
+        if (!f32) return in_is_f32 ? launch_sc_lanes<double, float>(c, P) : launch_sc_lanes<double, double>(c, P);
+        return in_is_f32 ? launch_sc_lanes<float, float>(c, P) : launch_sc_lanes<float, double>(c, P);
+    }
     if (fast_ok(c, in_is_f32)) {
         const bool crc = g.algo == POLAR_ALGO_CASCL;
         if (!f32) return launch_fast_n<double, double>(c, P, crc);
@@ -556,6 +591,10 @@ int polar_create(const polar_cfg *cfg, polar_ctx **out)
             snprintf(nm, sizeof nm, "k_scl_big<%s,L=%d>", cfg->dtype == POLAR_F32 ? "float" : "double", L);
             c->kernel_name = nm;
         }
+    }
+    if (cfg->algo == POLAR_ALGO_SC && !c->force_generic && N <= 1024) {
+        snprintf(nm, sizeof nm, "k_sc_lanes<%s> (batches of 64+; k_scl_generic below)", cfg->dtype == POLAR_F32 ? "float" : "double");
+        c->kernel_name = nm;
     }
     if (fast_ok(c, cfg->dtype == POLAR_F32)) {
         snprintf(nm, sizeof nm, "k_scl_fast%s<%s,N=%d,L=8>", (N == 1024 && c->use_fast2) ? "2" : "",

@@ -1,0 +1,211 @@
+// sc_lanes.h -- SC decoder, ONE CODEWORD PER LANE (reference: SCdecode, SC_128.c:395-460, SC_1024.c:434-498).
+//
+// SC has no list to manage, so nothing in it needs two lanes to talk: a wavefront decodes 64 codewords in
+// lock step, lane l working on frame 64*batch + l with the schedule (the frozen pattern) common to all lanes.
+// There is no cross-lane instruction, no divergence and no idle lane anywhere in the decoder.
+//
+//   LLR levels 0..4 (the 31 lowest values): registers, fully unrolled 32-leaf block (template recursion).
+//   LLR levels 5..n (n = channel): the wavefront's slice of a global scratch buffer, element e of level t at
+//     (2^t + e)*64 + lane -- every load and store of a level step is one coalesced 512-byte row.
+//     Plain stores, sc1 loads, s_waitcnt vmcnt(0) between a step and its consumer.
+//   Input rows [frame][N] are turned into that layout through a 32 x 64 LDS tile (coalesced on both sides).
+//   Partial sums: bits < 32 in a register, levels >= 5 as words [w][lane] in LDS.
+//   Subtrees without an information leaf are skipped altogether: their decisions are 0, their partial sums 0,
+//   and SC (unlike SCL) needs nothing else from them, so every decision and every LLR that IS computed is the
+//   reference's, operation for operation.
+#pragma once
+#include "polar_math.h"
+#include "polar_lut.h"
+#include "scl_generic.h"
+
+namespace polar {
+
+template <typename R>
+struct ScLanesCfg {
+    static constexpr int WAVES = 4;
+    static constexpr int TJ = 32;                                   // tile: 32 elements x 64 frames
+    static constexpr size_t tile_bytes = sizeof(R) * TJ * 65;
+    static constexpr size_t bits_bytes = 4 * 64 * (32 + 16);        // blw[32][64] + curw[16][64]
+    static constexpr size_t wave_bytes = ((tile_bytes > bits_bytes ? tile_bytes : bits_bytes) + 15) & ~(size_t)15;
+    static constexpr size_t lds_bytes = wave_bytes * WAVES + Lut<R>::bytes;
+    static constexpr size_t scratch_bytes(int N) { return sizeof(R) * 2 * (size_t)N * 64; }
+};
+
+template <typename R>
+struct ScLanes {
+    const Lut<R> &lut;
+    uint32_t fz;    // frozen mask of the current 32-leaf block (uniform)
+    uint32_t dec;   // decisions of the block, bit k = leaf k
+
+    // node of 2^T leaves starting at leaf K0 of the block, LLRs a[0..2^T); returns its partial sums
+    template <int T, int K0>
+    __device__ __forceinline__ uint32_t rec(const R *a)
+    {
+        constexpr uint32_t span = (T == 5) ? 0xFFFFFFFFu : ((1u << (1 << T)) - 1u);
+        if (((fz >> K0) & span) == span) return 0u;   // no information leaf below: decisions 0, partial sums 0
+        if constexpr (T == 0) {
+            const uint32_t bit = (a[0] < R(0)) ? 1u : 0u;   // SC_128.c:426-431 (l >= 0 -> 0)
+            dec |= bit << K0;
+            return bit;
+        } else {
+            constexpr int h = 1 << (T - 1);
+            constexpr uint32_t half = (1u << h) - 1u;
+            uint32_t bl = 0, br = 0;
+            if (((fz >> K0) & half) != half) {
+                R l[h];
+#pragma unroll
+                for (int e = 0; e < h; ++e) l[e] = chk_lut<R>(a[e], a[e + h], lut);
+                bl = rec<T - 1, K0>(l);
+            }
+            if (((fz >> (K0 + h)) & half) != half) {
+                R r[h];
+#pragma unroll
+                for (int e = 0; e < h; ++e) r[e] = gfun<R>(a[e], a[e + h], (bl >> e) & 1u);
+                br = rec<T - 1, K0 + h>(r);
+            }
+            return (bl ^ br) | (br << h);
+        }
+    }
+};
+
+template <typename R, typename IN>
+__global__ __launch_bounds__(256) void k_sc_lanes(SclParams P)
+{
+    using Cfg = ScLanesCfg<R>;
+    const int N = P.N, n = P.n, NW = N >> 5;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *mine = smem + (size_t)wave * Cfg::wave_bytes;
+    R *tile = reinterpret_cast<R *>(mine);                       // [TJ][65] while a batch is loaded
+    uint32_t *blw = reinterpret_cast<uint32_t *>(mine);          // [32][64] afterwards: saved left partial sums
+    uint32_t *curw = blw + 32 * 64;                              // [16][64] working partial sums
+    unsigned char *lut_mem = smem + (size_t)Cfg::WAVES * Cfg::wave_bytes;
+    Lut<R>::build(lut_mem, threadIdx.x, blockDim.x);
+    Lut<R> lut;
+    lut.bind(lut_mem);
+    __syncthreads();   // the waves of a workgroup share the tables and nothing else
+
+    const int slot = blockIdx.x * Cfg::WAVES + wave, nslots = gridDim.x * Cfg::WAVES;
+    R *lev = reinterpret_cast<R *>(reinterpret_cast<unsigned char *>(P.scratch) + (size_t)slot * Cfg::scratch_bytes(N)) + lane;
+    auto at = [&](int idx) -> R * { return lev + (size_t)idx * 64; };   // element idx = 2^t + e of this lane's codeword
+    auto sync = [] { __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
+    const int nbatch = (P.B + 63) >> 6;
+
+    for (int batch = slot; batch < nbatch; batch += nslots) {
+        const int frame0 = batch << 6;
+        // ---- channel LLRs (SC_128.c:416-420), transposed to [element][lane] through the LDS tile ----
+        for (int j0 = 0; j0 < N; j0 += Cfg::TJ) {
+            sync();
+#pragma unroll 4
+            for (int f = 0; f < 64; f += 2) {
+                const int fr = frame0 + f + (lane >> 5);
+                double v = 0.0;
+                if (fr < P.B) {
+                    v = (double)reinterpret_cast<const IN *>(P.in)[(size_t)fr * N + j0 + (lane & 31)];
+                    if (P.sigma > 0) v = llr_from_y(v, P.sigma);
+                }
+                tile[(lane & 31) * 65 + f + (lane >> 5)] = (R)v;
+            }
+            sync();
+#pragma unroll 4
+            for (int jj = 0; jj < Cfg::TJ; ++jj) *at(N + j0 + jj) = tile[jj * 65 + lane];
+        }
+        sync();
+
+        uint32_t fwv = 0;   // lane l: frozen word of block (b & ~63) + l
+        for (int b = 0; b < NW; ++b) {
+            if ((b & 63) == 0) fwv = (b + lane < NW) ? P.frozen[b + lane] : 0xFFFFFFFFu;
+            auto frozen_span = [&](int b0, int nwords) -> bool {   // all leaves of blocks b0 .. b0+nwords-1 frozen?
+                uint32_t all = 0xFFFFFFFFu;
+                for (int w = 0; w < nwords; ++w) all &= (uint32_t)__builtin_amdgcn_readlane((int)fwv, (b0 + w) & 63);
+                return all == 0xFFFFFFFFu;
+            };
+            // ---- levels n-1 .. 5 above this block: g at the level where the path turns right, f below it ----
+            int tf = n - 1;
+            bool live = true;   // does the subtree we are descending into hold an information leaf?
+            if (b > 0) {
+                const int d = __builtin_ctz((unsigned)b) + 5;
+                const int h = 1 << d;
+                live = !frozen_span(b, 1 << (d - 5));
+                if (live) {
+                    const uint32_t *bw = blw + (size_t)(h >> 5) * 64 + lane;   // left partial sums of level d
+                    for (int e0 = 0; e0 < h; e0 += 8) {
+                        R a[8], c[8];
+                        const uint32_t wv = bw[(size_t)(e0 >> 5) * 64];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            a[u] = ld_bypass(at(2 * h + e0 + u));
+                            c[u] = ld_bypass(at(2 * h + e0 + u + h));
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) *at(h + e0 + u) = gfun<R>(a[u], c[u], (wv >> ((e0 + u) & 31)) & 1u);
+                    }
+                    sync();
+                }
+                tf = d - 1;
+            }
+            for (int t = tf; t >= 5 && live; --t) {
+                const int h = 1 << t;
+                live = !frozen_span(b, 1 << (t - 5));
+                if (!live) break;
+                for (int e0 = 0; e0 < h; e0 += 8) {
+                    R a[8], c[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        a[u] = ld_bypass(at(2 * h + e0 + u));
+                        c[u] = ld_bypass(at(2 * h + e0 + u + h));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) *at(h + e0 + u) = chk_lut<R>(a[u], c[u], lut);
+                }
+                sync();
+            }
+            // ---- the 32-leaf block: level 5 from the scratch, levels 4..0 in registers ----
+            uint32_t beta = 0, dec = 0;
+            const uint32_t fz = (uint32_t)__builtin_amdgcn_readlane((int)fwv, b & 63);
+            if (live && fz != 0xFFFFFFFFu) {
+                ScLanes<R> S{lut, fz, 0u};
+                uint32_t bl = 0, br = 0;
+                if ((fz & 0xFFFFu) != 0xFFFFu) {
+                    R l[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) l[e] = chk_lut<R>(ld_bypass(at(32 + e)), ld_bypass(at(48 + e)), lut);
+                    bl = S.template rec<4, 0>(l);
+                }
+                if ((fz >> 16) != 0xFFFFu) {
+                    R r[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) r[e] = gfun<R>(ld_bypass(at(32 + e)), ld_bypass(at(48 + e)), (bl >> e) & 1u);
+                    br = S.template rec<4, 16>(r);
+                }
+                beta = (bl ^ br) | (br << 16);
+                dec = S.dec;
+            }
+            if (frame0 + lane < P.B) P.out_bits[(size_t)(frame0 + lane) * NW + b] = dec;   // frozen leaves stay 0
+            // ---- partial sums upwards (updateBit, SC_128.c:368-392): words [w][lane] in LDS ----
+            int t = 5;
+            curw[lane] = beta;
+            while (t < n - 1 && ((b >> (t - 5)) & 1)) {
+                const int nw = 1 << (t - 5);
+                for (int w = 0; w < nw; ++w) {
+                    const uint32_t c = curw[w * 64 + lane];
+                    const uint32_t l = blw[(nw + w) * 64 + lane];
+                    curw[w * 64 + lane] = l ^ c;
+                    curw[(w + nw) * 64 + lane] = c;
+                }
+                ++t;
+            }
+            if (t < n && !((b >> (t - 5)) & 1)) {
+                const int nw = 1 << (t - 5);
+                for (int w = 0; w < nw; ++w) blw[(nw + w) * 64 + lane] = curw[w * 64 + lane];
+            }
+        }
+        if (lane == 0 || true) {
+            if (P.pm && frame0 + lane < P.B) P.pm[frame0 + lane] = 0.0;
+            if (P.flags && frame0 + lane < P.B) P.flags[frame0 + lane] = 0u;
+        }
+    }
+}
+
+}  // namespace polar

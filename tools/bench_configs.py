@@ -19,7 +19,7 @@ def llrs(B, N):
     return (2 * y / sigma / sigma).to(tdt).contiguous()
 
 CONFIGS = [
-    ("SC_1024", lambda: pa.SCdecode(1024, 512, dtype=dt), 1024, 1 << 14),
+    ("SC_1024", lambda: pa.SCdecode(1024, 512, dtype=dt), 1024, 1 << 18),
     ("BP_1024_50it", lambda: pa.BP(1024, 512, iterMax=50, dtype=dt), 1024, 1 << 13),
     ("SCL_1024_L8", lambda: pa.SCLdecode(1024, 512, L=8, dtype=dt), 1024, 1 << 16),
     ("CASCL_1024_L8", lambda: pa.CASCL(1024, 512, L=8, dtype=dt), 1024, 1 << 17),
