@@ -18,7 +18,7 @@ for sub in sorted(glob.glob(f"{d}/pmc*")):
         disp = collections.defaultdict(set)
         for r in rows:
             kn = r["Kernel_Name"]
-            if "k_scl" in kn or "k_bp" in kn:
+            if "polar::k_" in kn and "k_count" not in kn and "k_generate" not in kn:
                 kn = kn.split("(")[0].replace("void polar::", "")
                 agg[kn][r["Counter_Name"]] += float(r["Counter_Value"])
                 disp[kn].add(r["Dispatch_Id"])
