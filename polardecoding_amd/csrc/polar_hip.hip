@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,11 @@ struct polar_ctx {
     bool own_stream = false;
     int num_cu = 0;
     Buf in, bits, pm, flags;              // staging for the host-pointer entry points
+    Buf in2[2], bits2[2];                 // chunked host pipeline: ping-pong device buffers
+    uint32_t *h_bits[2] = {nullptr, nullptr};   // pinned host copies of the packed decisions
+    size_t h_bits_cap = 0;
+    hipStream_t copy_stream = nullptr;    // host -> device copies overlap the decode of the previous chunk
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     Buf scratch;                          // k_scl_fast per-wave scratch
     Buf gen_llr, gen_u, gen_cnt;          // polar_fer_batch
     std::string last_error;
@@ -412,6 +418,25 @@ std::vector<uint32_t> pack_mask(const unsigned char *m, int N, bool invert)
     return w;
 }
 
+// packed decisions -> the reference's int u_hat[N] (0/1), eight bits per table look-up
+void unpack_words(const uint32_t *w, int NW, int *out)
+{
+    struct Row { int v[8]; };
+    static const std::vector<Row> tab = [] {
+        std::vector<Row> t(256);
+        for (int b = 0; b < 256; ++b)
+            for (int k = 0; k < 8; ++k) t[(size_t)b].v[k] = (b >> k) & 1;
+        return t;
+    }();
+    for (int i = 0; i < NW; ++i) {
+        const uint32_t x = w[i];
+        std::memcpy(out + 32 * i, &tab[x & 255u], sizeof(Row));
+        std::memcpy(out + 32 * i + 8, &tab[(x >> 8) & 255u], sizeof(Row));
+        std::memcpy(out + 32 * i + 16, &tab[(x >> 16) & 255u], sizeof(Row));
+        std::memcpy(out + 32 * i + 24, &tab[x >> 24], sizeof(Row));
+    }
+}
+
 int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char *frozen_mask, size_t B,
                int *u_hat, double *pm_out, unsigned *flags)
 {
@@ -429,21 +454,84 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
         d_frozen = c->d_frozen_override;
     }
     int rc;
-    if ((rc = ensure(c, c->in, B * N * sizeof(double)))) return rc;
-    if ((rc = ensure(c, c->bits, B * NW * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c, c->pm, B * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->flags, B * sizeof(uint32_t)))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->in.p, in, B * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    rc = decode_device_impl(c, c->in.p, 0, sigma, B, (uint32_t *)c->bits.p, (double *)c->pm.p,
-                            (uint32_t *)c->flags.p, d_frozen);
-    if (rc) return rc;
-    std::vector<uint32_t> hb(B * NW);
-    HIP_TRY(c, hipMemcpyAsync(hb.data(), c->bits.p, B * NW * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    // Chunked pipeline: while chunk k is decoded, chunk k+1 crosses PCIe on a second stream and the decisions of
+    // chunk k-1 are unpacked to the caller's int array by helper threads.  The input is pageable caller memory,
+    // so the copy blocks this thread; that is why the unpacking has its own.
+    const size_t CH = 16384;
+    const size_t nch = (B + CH - 1) / CH;
+    const size_t chf = std::min(B, CH);
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = ensure(c, c->in2[i], chf * N * sizeof(double)))) return rc;
+        if ((rc = ensure(c, c->bits2[i], chf * NW * sizeof(uint32_t)))) return rc;
+    }
+    if (c->h_bits_cap < chf * NW * sizeof(uint32_t)) {
+        for (int i = 0; i < 2; ++i) {
+            if (c->h_bits[i]) HIP_TRY(c, hipHostFree(c->h_bits[i]));
+            c->h_bits[i] = nullptr;
+            HIP_TRY(c, hipHostMalloc((void **)&c->h_bits[i], chf * NW * sizeof(uint32_t), hipHostMallocDefault));
+        }
+        c->h_bits_cap = chf * NW * sizeof(uint32_t);
+    }
+    if (!c->copy_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
+        }
+    }
+    std::thread worker;
+    auto unpack_chunk = [&](size_t k) {   // decisions of chunk k: pinned words -> caller's int u_hat[][N]
+        const size_t f0 = k * CH, nf = std::min(CH, B - f0);
+        const uint32_t *hb = c->h_bits[k & 1];
+        const unsigned nthr = (unsigned)std::max<size_t>(1, std::min<size_t>(4, nf / 1024));
+        auto part = [=](unsigned t) {
+            const size_t a = nf * t / nthr, b = nf * (t + 1) / nthr;
+            for (size_t f = a; f < b; ++f) unpack_words(hb + f * NW, NW, u_hat + (f0 + f) * (size_t)N);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(part, t);
+        part(0);
+        for (auto &th : pool) th.join();
+    };
+    auto fail_join = [&](int code) {
+        if (worker.joinable()) worker.join();
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamSynchronize(c->stream);
+        return code;
+    };
+    for (size_t k = 0; k < nch; ++k) {
+        const int s = (int)(k & 1);
+        const size_t f0 = k * CH, nf = std::min(CH, B - f0);
+        // the decode of chunk k-2 must be done with in2[s] before it is overwritten
+        if (k >= 2 && hipStreamWaitEvent(c->copy_stream, c->ev_free[s], 0) != hipSuccess) return fail_join(POLAR_EDEVICE);
+        if (hipMemcpyAsync(c->in2[s].p, in + f0 * (size_t)N, nf * N * sizeof(double), hipMemcpyHostToDevice,
+                           c->copy_stream) != hipSuccess) return fail_join(POLAR_EDEVICE);
+        if (hipEventRecord(c->ev_in[s], c->copy_stream) != hipSuccess) return fail_join(POLAR_EDEVICE);
+        if (hipStreamWaitEvent(c->stream, c->ev_in[s], 0) != hipSuccess) return fail_join(POLAR_EDEVICE);
+        // h_bits[s] / bits2[s] were last used by chunk k-2, whose unpacking ran during the copy above
+        if (worker.joinable()) worker.join();
+        rc = decode_device_impl(c, c->in2[s].p, 0, sigma, nf, (uint32_t *)c->bits2[s].p, (double *)c->pm.p + f0,
+                                (uint32_t *)c->flags.p + f0, d_frozen);
+        if (rc) return fail_join(rc);
+        if (hipEventRecord(c->ev_free[s], c->stream) != hipSuccess) return fail_join(POLAR_EDEVICE);
+        if (hipMemcpyAsync(c->h_bits[s], c->bits2[s].p, nf * NW * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) !=
+            hipSuccess) return fail_join(POLAR_EDEVICE);
+        if (hipEventRecord(c->ev_out[s], c->stream) != hipSuccess) return fail_join(POLAR_EDEVICE);
+        // chunk k-1 was decoded while chunk k crossed PCIe: unpack it in the background during the next copy
+        if (k >= 1) {
+            if (hipEventSynchronize(c->ev_out[s ^ 1]) != hipSuccess) return fail_join(POLAR_EDEVICE);
+            worker = std::thread(unpack_chunk, k - 1);
+        }
+    }
+    if (worker.joinable()) worker.join();
+    HIP_TRY(c, hipEventSynchronize(c->ev_out[(nch - 1) & 1]));
+    unpack_chunk(nch - 1);
     if (pm_out) HIP_TRY(c, hipMemcpyAsync(pm_out, c->pm.p, B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (flags) HIP_TRY(c, hipMemcpyAsync(flags, c->flags.p, B * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (size_t b = 0; b < B; ++b)
-        for (int j = 0; j < N; ++j) u_hat[b * N + j] = (int)((hb[b * NW + (j >> 5)] >> (j & 31)) & 1u);
     return POLAR_OK;
 }
 
@@ -610,8 +698,17 @@ void polar_destroy(polar_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (Buf *b : {&c->in, &c->bits, &c->pm, &c->flags, &c->scratch, &c->gen_llr, &c->gen_u, &c->gen_cnt})
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (Buf *b : {&c->in, &c->bits, &c->pm, &c->flags, &c->scratch, &c->gen_llr, &c->gen_u, &c->gen_cnt, &c->in2[0],
+                   &c->in2[1], &c->bits2[0], &c->bits2[1]})
         if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < 2; ++i) {
+        if (c->h_bits[i]) (void)hipHostFree(c->h_bits[i]);
+        if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
+        if (c->ev_free[i]) (void)hipEventDestroy(c->ev_free[i]);
+        if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->d_frozen) (void)hipFree(c->d_frozen);
     if (c->d_info) (void)hipFree(c->d_info);
     if (c->d_crc_tab) (void)hipFree(c->d_crc_tab);
