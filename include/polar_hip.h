@@ -116,6 +116,16 @@ int polar_decode_device(polar_ctx *ctx, const void *d_in, int in_is_f32, double 
 int polar_count_errors_device(polar_ctx *ctx, const uint32_t *d_uhat_bits, const uint32_t *d_u_bits, size_t B,
                               unsigned long long *d_counters, uint32_t *d_frame_err);
 
+/* --- BP with per-stage read-outs (BPr_128.c:373-575: `BPr(y, u_hat, u)` and its table E[7][n+1]) -----------------
+ * ctx must be a POLAR_ALGO_BP context (its bp_iters = the program's iterMax, 90 in BPr_128.c:16).  After each of the
+ * iteration counts checkpoints[0..ncp) (ascending, <= 8; the program uses 3, 6, 10, 20, 40, 80, :18-23) the hard
+ * decisions of l + r at every stage i = 0..n are carried back to the u side and compared with the sent bits on the
+ * information set; d_E[c*(n+1) + i] accumulates the mismatches over the B frames (the program's E[c][i], :437).
+ * d_u_bits: [B][N/32] sent bits; d_uhat_bits (may be NULL): [B][N/32] final decisions.  N <= 512 (f64), 1024 (f32). */
+int polar_bp_readout_device(polar_ctx *ctx, const void *d_in, int in_is_f32, double sigma, size_t B,
+                            const uint32_t *d_u_bits, const int *checkpoints, int ncp, unsigned long long *d_E,
+                            uint32_t *d_uhat_bits);
+
 /* --- device-side transmit chain, throughput mode (the frame loop of main(), CASCL_1024_L8.c:245-292) -----------
  * Fills B frames: random payload -> CRC multiply by g(D) -> u[I[i]] -> x = u F^{(x)n} -> BPSK + AWGN at
  * Eb/N0 = snr_db (sigma = 10^(-snr_db/20), rate 1/2 as in the reference, :237) -> d_out[B][N] (double, or float

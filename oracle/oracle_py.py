@@ -182,6 +182,24 @@ class Sim:
         return (int(self._s.ranv), int(self._s.rani), int(self._s.m))
 
 
+def bp_readout(code, llr, u, iters, checkpoints):
+    """BPr_128.c: BP with per-stage read-outs.  llr [B][N], u [B][N] -> (u_hat [B][N], E [len(cp)][n+1] summed over B)."""
+    L_ = lib()
+    L_.po_bpr_decode_f64.argtypes = [C.POINTER(_Code), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.c_int,
+                                     C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_int)]
+    llr = np.ascontiguousarray(llr, dtype=np.float64).reshape(-1, code.N)
+    u = np.ascontiguousarray(u, dtype=np.int32).reshape(-1, code.N)
+    cp = np.asarray(checkpoints, dtype=np.int32)
+    E = np.zeros((len(cp), code.n + 1), dtype=np.int64)
+    uh = np.zeros_like(u)
+    for b in range(llr.shape[0]):
+        rc = L_.po_bpr_decode_f64(code._h, _dp(llr[b]), iters, _ip(cp), len(cp), _ip(u[b]),
+                                  E.ctypes.data_as(C.POINTER(C.c_long)), _ip(uh[b]))
+        if rc != 0:
+            raise RuntimeError(f"po_bpr_decode rc={rc}")
+    return uh, E
+
+
 def run_sweep(code, algo, snr_db, ble, seed, L=8, bp_iters=100):
     snr = np.asarray(snr_db, dtype=np.float64)
     run = (C.c_long * len(snr))()
@@ -241,6 +259,26 @@ class Ref:
         uh = np.zeros(self.N, dtype=np.int32)
         self.l.ref_decode(_dp(y), sigma, _ip(uh))
         return uh, self.l.ref_last_pm()
+
+    # --- BPr_128.c only (oracle/Makefile kind 4): BPr(y, u_hat, u) and its read-out table E[7][n+1] ---
+    def readout_iters(self):
+        cp = (C.c_int * 6)()
+        iters = self.l.ref_readout_iters(cp)
+        return iters, list(cp)
+
+    def decode_u(self, y, sigma, u):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.int32)
+        uh = np.zeros(self.N, dtype=np.int32)
+        self.l.ref_decode_u.argtypes = [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        self.l.ref_decode_u(_dp(y), sigma, _ip(u), _ip(uh))
+        return uh
+
+    def readout(self, reset=True):
+        n = int(np.log2(self.N))
+        e = np.zeros((7, n + 1), dtype=np.int32)
+        self.l.ref_readout(_ip(e), 1 if reset else 0)
+        return e[:6]
 
     def time_decode(self, ys, sigma):
         ys = np.ascontiguousarray(ys, dtype=np.float64)

@@ -57,6 +57,9 @@ void po_llr_from_y(const double *y, double sigma, double *llr, int N);
  * Return 0 on success. */
 int po_sc_decode_f64(const po_code *c, const double *llr, int *u_hat);            /* SC_128.c:395-460 */
 int po_bp_decode_f64(const po_code *c, const double *llr, int iters, int *u_hat); /* BP_1024.c:372-427 */
+/* BPr_128.c:373-575: BP with per-stage read-outs after the iteration counts cp[0..ncp); E[ncp][n+1] accumulates */
+int po_bpr_decode_f64(const po_code *c, const double *llr, int iters, const int *cp, int ncp, const int *u,
+                      long *E, int *u_hat);
 /* crc != 0 -> CASCL selection rule (CASCL_1024_L8.c:725-755), else SCLdecode's arg-min (SCL_1024.c:667-678).
  * pm_out (nullable) = metric of the chosen path; ties_out (nullable) = number of median-tie events. */
 int po_scl_decode_f64(const po_code *c, const double *llr, int L, int crc, int *u_hat,

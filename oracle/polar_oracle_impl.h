@@ -101,7 +101,12 @@ int FN(po_sc_decode)(const po_code *c, const REAL *llr, int *u_hat)
  * BP (BP_1024.c:372-427): flooding schedule, iters round trips, no early stop (Appendix A.4).
  * l, r: [n+1][N].  Operand order inside the sums and CHK calls kept as in the reference.
  * ---------------------------------------------------------------------------------------- */
-int FN(po_bp_decode)(const po_code *c, const REAL *llr, int iters, int *u_hat)
+/* BPr (BPr_128.c:373-575): the same flooding BP, and after the iterations listed in cp[] (1-based counts,
+ * reference: 3, 6, 10, 20, 40, 80 of iterMax = 90, :18-23) a read-out per stage i = 0..n (:417-438): hard
+ * decisions of l+r at stage i, carried back to the u side through the inverse butterflies of stages i-1..0,
+ * compared with the sent bits on the information set; E[c][i] += mismatches.  cp == NULL: plain BP. */
+int FN(po_bpr_decode)(const po_code *c, const REAL *llr, int iters, const int *cp, int ncp, const int *u,
+                      long *E /* [ncp][n+1], accumulated */, int *u_hat)
 {
     const int N = c->N, n = c->n;
     REAL *l = (REAL *)calloc((size_t)(n + 1) * N, sizeof(REAL));
@@ -132,6 +137,21 @@ int FN(po_bp_decode)(const po_code *c, const REAL *llr, int iters, int *u_hat)
                 Lm(i, j + s) = b;
             }
         }
+        for (int q = 0; q < ncp; q++) {
+            if (cp[q] != it + 1) continue;
+            int *b = (int *)malloc(sizeof(int) * (size_t)N);
+            for (int i = 0; i <= n; i++) {
+                for (int j = 0; j < N; j++) b[j] = (Lm(i, j) + Rm(i, j) >= 0) ? 0 : 1;
+                for (int k = i; k > 0; k--) { /* :423-429: left = (upper ^ lower, lower) of the stage k-1 butterflies */
+                    int s = 1 << (k - 1);
+                    for (int j = 0; j < N; j++)
+                        if (!(j & s)) b[j] = (b[j + s] + b[j]) % 2;
+                }
+                for (int j = 0; j < c->K; j++)
+                    if (b[c->info_order[j]] != u[c->info_order[j]]) E[(size_t)q * (n + 1) + i] += 1;
+            }
+            free(b);
+        }
     }
     for (int j = 0; j < N; j++) /* BP_1024.c:417-425 */
         u_hat[j] = c->frozen[j] ? 0 : ((Lm(0, j) + Rm(0, j) >= 0) ? 0 : 1);
@@ -139,6 +159,11 @@ int FN(po_bp_decode)(const po_code *c, const REAL *llr, int iters, int *u_hat)
 #undef Rm
     free(l); free(r);
     return 0;
+}
+
+int FN(po_bp_decode)(const po_code *c, const REAL *llr, int iters, int *u_hat)
+{
+    return FN(po_bpr_decode)(c, llr, iters, NULL, 0, NULL, NULL, u_hat);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -7,7 +7,7 @@
  *
  *   -DREF_SRC="\"/root/reference/CASCL_1024_L8.c\""   the translation unit to wrap
  *   -DREF_DECODE=CASCL                                  its decode entry point
- *   -DREF_KIND=3                                        0 SC, 1 BP, 2 SCL, 3 CASCL
+ *   -DREF_KIND=3                                        0 SC, 1 BP, 2 SCL, 3 CASCL, 4 BP with per-stage read-outs (BPr_128.c)
  *   -DREF_BITREV                                        the program decodes on the bit-reversed graph (CASCL_1024_sys.c)
  *
  * What is restated here (because the reference keeps it inline in main(), SCL_1024.c:159-217) is
@@ -43,7 +43,7 @@ static int ref_scanf_int(int *dst)
  * global noise deviation: no local identifier below may use those names. */
 
 enum { REF_BLOCK = N, REF_INFO = K, REF_LOG = n };
-#if REF_KIND >= 2
+#if REF_KIND == 2 || REF_KIND == 3
 enum { REF_LIST = L };
 #else
 enum { REF_LIST = 1 };
@@ -68,7 +68,7 @@ int ref_init(void)
 {
     int a, b;
     if (ref_ready) return 0;
-#if REF_KIND >= 2
+#if REF_KIND == 2 || REF_KIND == 3
     PM = (double *)calloc(2 * REF_LIST, sizeof(double));
     PMcand = (double *)calloc(2 * REF_LIST, sizeof(double));
 #endif
@@ -109,6 +109,27 @@ int ref_init(void)
 }
 
 /* One call of the reference decoder: y = channel observations, sigma -> global `std`. */
+#if REF_KIND == 4
+/* BPr_128.c: BPr(y, u_hat, u) also takes the sent bits and accumulates the per-stage read-outs in E[7][n+1] */
+int ref_decode_u(const double *y, double sigma, const int *u, int *u_hat)
+{
+    if (!ref_ready) ref_init();
+    std = sigma;
+    REF_DECODE((double *)y, u_hat, (int *)u);
+    return 0;
+}
+int ref_decode(const double *y, double sigma, int *u_hat) { return -1; }
+void ref_readout(int *out, int reset)
+{
+    int a, b;
+    for (a = 0; a < 7; a++)
+        for (b = 0; b <= REF_LOG; b++) {
+            out[a * (REF_LOG + 1) + b] = E[a][b];
+            if (reset) E[a][b] = 0;
+        }
+}
+int ref_readout_iters(int *cp) { cp[0] = i0; cp[1] = i1; cp[2] = i2; cp[3] = i3; cp[4] = i4; cp[5] = i5; return iterMax; }
+#else
 int ref_decode(const double *y, double sigma, int *u_hat)
 {
     if (!ref_ready) ref_init();
@@ -116,6 +137,7 @@ int ref_decode(const double *y, double sigma, int *u_hat)
     REF_DECODE((double *)y, u_hat);
     return 0;
 }
+#endif
 
 /* Path metric of the path the list decoders just chose (same selection rule as the decoder). */
 double ref_last_pm(void)
@@ -149,7 +171,11 @@ double ref_time_decode(const double *y, double sigma, long count, int *u_hat_las
     if (!ref_ready) ref_init();
     std = sigma;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+#if REF_KIND == 4
+    (void)f;
+#else
     for (f = 0; f < count; f++) REF_DECODE((double *)(y + f * (long)REF_BLOCK), u_hat_last);
+#endif
     clock_gettime(CLOCK_MONOTONIC, &t1);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

@@ -70,6 +70,7 @@ def load_library():
     L.polar_decode_batch_y.argtypes = [vp, dp, C.c_double, C.c_size_t, ip, dp, up]
     L.polar_decode_device.argtypes = [vp, vp, C.c_int, C.c_double, C.c_size_t, vp, vp, vp]
     L.polar_count_errors_device.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
+    L.polar_bp_readout_device.argtypes = [vp, vp, C.c_int, C.c_double, C.c_size_t, vp, ip, C.c_int, vp, vp]
     L.polar_generate_device.argtypes = [vp, C.c_ulonglong, C.c_ulonglong, C.c_double, C.c_size_t, vp, C.c_int,
                                         C.c_int, vp]
     L.polar_fer_batch.argtypes = [vp, C.c_ulonglong, C.c_ulonglong, C.c_double, C.c_size_t, C.POINTER(C.c_ulonglong),
@@ -246,6 +247,17 @@ class Decoder:
             self._h, C.c_void_p(uhat_bits.data_ptr()), C.c_void_p(u_bits.data_ptr()), B,
             C.c_void_p(counters.data_ptr()),
             C.c_void_p(frame_err.data_ptr()) if frame_err is not None else None), "polar_count_errors_device")
+
+    def bp_readout_device(self, d_in, u_bits, checkpoints, E, out_bits=None, sigma=0.0):
+        """BPr_128.c: BP with per-stage read-outs.  d_in [B][N] LLR (or y with sigma), u_bits [B][N/32] int32 sent
+        bits, E int64 [len(checkpoints)][n+1] accumulated on the device, out_bits optional [B][N/32]."""
+        import torch
+        B = d_in.numel() // self.N
+        cp = (C.c_int * len(checkpoints))(*[int(x) for x in checkpoints])
+        self._check(self._lib.polar_bp_readout_device(
+            self._h, C.c_void_p(d_in.data_ptr()), 1 if d_in.dtype == torch.float32 else 0, float(sigma), B,
+            C.c_void_p(u_bits.data_ptr()), cp, len(checkpoints), C.c_void_p(E.data_ptr()),
+            C.c_void_p(out_bits.data_ptr()) if out_bits is not None else None), "polar_bp_readout_device")
 
     def time_decode_device(self, d_in, out_bits, reps, sigma=0.0):
         import torch

@@ -155,6 +155,126 @@ constexpr size_t bp_lds_bytes(int N, int n)
     return sizeof(R) * (size_t)N * (1 + 2 * (n - 1)) + sizeof(uint32_t) * (size_t)(N / 32) + 16 + Lut<R>::bytes;
 }
 
+// ---- BP with per-stage read-outs (reference: BPr, BPr_128.c:373-575) -------------------------
+// The same flooding schedule with every row kept (the read-out of stage i needs l[i] + r[i] for i = 0..n, so
+// r[n] and l[0] are computed in every iteration as the reference does), one codeword per workgroup, N/2 threads.
+// After the iterations listed in cp[] the hard decisions of every stage are carried back to the u side through
+// the inverse butterflies (:417-438) and compared with the sent bits on the information set.
+struct BpReadoutParams {
+    const void *in;           // [B][N] LLR, or y when sigma > 0
+    double sigma;
+    uint32_t *out_bits;       // [B][N/32] final decisions (may be null)
+    const uint32_t *frozen;   // [N/32]
+    const uint32_t *info;     // [N/32] 1 = information position
+    const uint32_t *u_bits;   // [B][N/32] sent bits
+    unsigned long long *E;    // [ncp][n+1], accumulated over the frames of the launch
+    int cp[8];                // iteration counts (1-based), ascending
+    int ncp;
+    int N, n, B, iters;
+};
+
+template <typename R, typename IN>
+__global__ __launch_bounds__(256) void k_bp_readout(BpReadoutParams P)
+{
+    const int N = P.N, n = P.n, NW = N >> 5;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    R *lm = reinterpret_cast<R *>(smem);                 // l[0..n][N]
+    R *rm = lm + (size_t)(n + 1) * N;                     // r[0..n][N]
+    unsigned char *bb = reinterpret_cast<unsigned char *>(rm + (size_t)(n + 1) * N);   // [N] read-out bits
+    uint32_t *obits = reinterpret_cast<uint32_t *>(bb + N);                            // [NW]
+    uint32_t *cnt = obits + NW;                                                        // [1]
+    unsigned char *lut_mem = reinterpret_cast<unsigned char *>(cnt + 4);
+    lut_mem += (16 - (reinterpret_cast<uintptr_t>(lut_mem) & 15)) & 15;
+    Lut<R>::build(lut_mem, tid, nt);
+    Lut<R> lut;
+    lut.bind(lut_mem);
+    __syncthreads();
+#define LM(i, j) lm[(size_t)(i) * N + (j)]
+#define RM(i, j) rm[(size_t)(i) * N + (j)]
+    for (int frame = blockIdx.x; frame < P.B; frame += gridDim.x) {
+        const IN *src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
+        for (int i = tid; i < (n + 1) * N; i += nt) {
+            lm[i] = R(0);   // BPr_128.c:379-381
+            rm[i] = R(0);   // :385-387
+        }
+        __syncthreads();
+        for (int j = tid; j < N; j += nt) {
+            double v = (double)src[j];
+            if (P.sigma > 0) v = llr_from_y(v, P.sigma);
+            LM(n, j) = (R)v;                                                        // :382-383
+            RM(0, j) = ((P.frozen[j >> 5] >> (j & 31)) & 1) ? R(999) : R(0);        // :388-393
+        }
+        for (int i = tid; i < NW; i += nt) obits[i] = 0;
+        __syncthreads();
+        int q = 0;
+        for (int it = 0; it < P.iters; ++it) {
+            for (int i = 0; i < n; ++i) {   // R sweep (:396-405)
+                const int s = 1 << i;
+                for (int b = tid; b < N / 2; b += nt) {
+                    const int j = ((b >> i) << (i + 1)) | (b & (s - 1));
+                    const R r0 = RM(i, j), r1 = RM(i, j + s), l0 = LM(i + 1, j), l1 = LM(i + 1, j + s);
+                    RM(i + 1, j) = chk_lut<R>(r0, l1 + r1, lut);
+                    RM(i + 1, j + s) = r1 + chk_lut<R>(r0, l0, lut);
+                }
+                __syncthreads();
+            }
+            for (int i = n - 1; i >= 0; --i) {   // L sweep (:406-415)
+                const int s = 1 << i;
+                for (int b = tid; b < N / 2; b += nt) {
+                    const int j = ((b >> i) << (i + 1)) | (b & (s - 1));
+                    const R r0 = RM(i, j), r1 = RM(i, j + s), l0 = LM(i + 1, j), l1 = LM(i + 1, j + s);
+                    LM(i, j) = chk_lut<R>(l0, l1 + r1, lut);
+                    LM(i, j + s) = l1 + chk_lut<R>(r0, l0, lut);
+                }
+                __syncthreads();
+            }
+            if (q < P.ncp && P.cp[q] == it + 1) {   // read-out (:417-438)
+                for (int i = 0; i <= n; ++i) {
+                    if (tid == 0) cnt[0] = 0;
+                    for (int j = tid; j < N; j += nt) bb[j] = (LM(i, j) + RM(i, j) >= R(0)) ? 0 : 1;
+                    __syncthreads();
+                    for (int k = i; k > 0; --k) {
+                        const int s = 1 << (k - 1);
+                        for (int b = tid; b < N / 2; b += nt) {
+                            const int j = ((b >> (k - 1)) << k) | (b & (s - 1));
+                            bb[j] ^= bb[j + s];
+                        }
+                        __syncthreads();
+                    }
+                    uint32_t e = 0;
+                    for (int j = tid; j < N; j += nt) {
+                        const uint32_t sent = (P.u_bits[(size_t)frame * NW + (j >> 5)] >> (j & 31)) & 1u;
+                        const uint32_t isinfo = (P.info[j >> 5] >> (j & 31)) & 1u;
+                        e += isinfo & (sent ^ (uint32_t)bb[j]);
+                    }
+                    if (e) atomicAdd(&cnt[0], e);
+                    __syncthreads();
+                    if (tid == 0 && cnt[0]) atomicAdd(&P.E[(size_t)q * (n + 1) + i], (unsigned long long)cnt[0]);
+                    __syncthreads();
+                }
+                ++q;
+            }
+        }
+        for (int j = tid; j < N; j += nt) {   // :566-574
+            const bool fr = (P.frozen[j >> 5] >> (j & 31)) & 1;
+            if (!fr && !(LM(0, j) + RM(0, j) >= R(0))) atomicOr(&obits[j >> 5], 1u << (j & 31));
+        }
+        __syncthreads();
+        if (P.out_bits)
+            for (int i = tid; i < NW; i += nt) P.out_bits[(size_t)frame * NW + i] = obits[i];
+        __syncthreads();
+    }
+#undef LM
+#undef RM
+}
+
+template <typename R>
+constexpr size_t bp_readout_lds_bytes(int N, int n)
+{
+    return sizeof(R) * 2 * (size_t)(n + 1) * N + (size_t)N + 4 * (size_t)(N / 32) + 16 + 16 + Lut<R>::bytes;
+}
+
 // ---- error accounting (main()'s compare loop, CASCL_1024_L8.c:296-305) -------------------------------
 // One thread per frame word would be enough; one wave per frame keeps it trivially coalesced.
 struct CountParams {

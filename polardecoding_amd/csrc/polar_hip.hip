@@ -351,6 +351,25 @@ int launch_bp(polar_ctx *c, const polar::BpParams &P)
     return POLAR_OK;
 }
 
+template <typename R, typename IN>
+int launch_bp_readout(polar_ctx *c, const polar::BpReadoutParams &P)
+{
+    auto kern = polar::k_bp_readout<R, IN>;
+    const size_t lds = polar::bp_readout_lds_bytes<R>(P.N, P.n);
+    if (lds > 160 * 1024) return POLAR_ENOKERNEL;
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    const int threads = std::max(64, std::min(256, P.N / 2));
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds));
+    if (occ < 1) occ = 1;
+    int grid = (int)std::min<long long>((long long)P.B, (long long)occ * c->num_cu);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, P);
+    HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
 int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sigma, size_t B, uint32_t *d_bits,
                        double *d_pm, uint32_t *d_flags, const uint32_t *d_frozen)
 {
@@ -822,6 +841,28 @@ int polar_decode_llr(const double *llr_in, const unsigned char *frozen_mask, int
         cache.emplace_back(key, c);
     }
     return host_batch(c, llr_in, 0.0, nullptr, 1, u_hat, nullptr, nullptr);
+}
+
+int polar_bp_readout_device(polar_ctx *c, const void *d_in, int in_is_f32, double sigma, size_t B,
+                            const uint32_t *d_u_bits, const int *checkpoints, int ncp, unsigned long long *d_E,
+                            uint32_t *d_uhat_bits)
+{
+    if (!c || !d_in || !d_u_bits || !checkpoints || !d_E) return POLAR_EINVAL;
+    if (c->cfg.algo != POLAR_ALGO_BP || ncp < 1 || ncp > 8 || B > 0x7fffffffull) return POLAR_EINVAL;
+    if (B == 0) return POLAR_OK;
+    polar::BpReadoutParams P{};
+    for (int i = 0; i < ncp; ++i) {
+        if (checkpoints[i] < 1 || checkpoints[i] > c->cfg.bp_iters || (i && checkpoints[i] <= checkpoints[i - 1]))
+            return POLAR_EINVAL;
+        P.cp[i] = checkpoints[i];
+    }
+    P.ncp = ncp;
+    P.in = d_in; P.sigma = sigma; P.out_bits = d_uhat_bits; P.frozen = c->d_frozen; P.info = c->d_info;
+    P.u_bits = d_u_bits; P.E = d_E;
+    P.N = c->cfg.N; P.n = c->n; P.B = (int)B; P.iters = c->cfg.bp_iters;
+    if (c->cfg.dtype == POLAR_F32)
+        return in_is_f32 ? launch_bp_readout<float, float>(c, P) : launch_bp_readout<float, double>(c, P);
+    return in_is_f32 ? launch_bp_readout<double, float>(c, P) : launch_bp_readout<double, double>(c, P);
 }
 
 int polar_count_errors_device(polar_ctx *c, const uint32_t *d_uhat, const uint32_t *d_u, size_t B,

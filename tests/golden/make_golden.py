@@ -80,6 +80,28 @@ def check_systematic_rows(name, code):
     print(f"{name}: {len(rows)} generator rows equal D^(r+i) mod g")
 
 
+def make_bpr():
+    """BPr_128.c: BP (iterMax 90) with per-stage read-outs after 3, 6, 10, 20, 40, 80 iterations.
+    BPr_128.npz: sigma[F], y[F][N], u[F][N], u_hat[F][N], iters, checkpoints[6], E[F][6][n+1] (per frame)."""
+    name = "BPr_128"
+    ref = O.Ref(name)
+    iters, cp = ref.readout_iters()
+    code = O.Code(128, 64)
+    sim = O.Sim(20261004 + 128 + len(name))
+    sig, ys, us, uhs, Es = [], [], [], [], []
+    ref.readout(reset=True)
+    for db in SNRS:
+        s = O.sigma_from_db(db)
+        for _ in range(16):
+            u, y = sim.frame(code, s)
+            uh = ref.decode_u(y, s, u)
+            sig.append(s); ys.append(y); us.append(u); uhs.append(uh); Es.append(ref.readout(reset=True))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), sigma=np.array(sig), y=np.array(ys),
+                        u=np.array(us, dtype=np.uint8), u_hat=np.array(uhs, dtype=np.uint8), iters=iters,
+                        checkpoints=np.array(cp), E=np.array(Es))
+    print(f"{name}: {len(sig)} frames, iterMax {iters}, checkpoints {cp}, E total\n{np.array(Es).sum(axis=0)}")
+
+
 def parse_log(text):
     """-> list of blocks {seed, L, rows:[(snr, errblock, run)]}"""
     blocks, cur = [], None
@@ -121,6 +143,9 @@ def make_published():
 
 
 if __name__ == "__main__":
-    make_vectors(sys.argv[1:] or None)   # optional: names of the programs to regenerate
-    if len(sys.argv) == 1:
+    only = sys.argv[1:] or None          # optional: names of the programs to regenerate
+    make_vectors(only)
+    if not only or "BPr_128" in only:
+        make_bpr()
+    if not only:
         make_published()

@@ -242,3 +242,59 @@ def test_device_path_and_error_count(oracle):
     exp = np.array([oracle.count_bit_errors(code, us[b], ref_uh[b]) for b in range(B)])
     assert np.array_equal(ferr.cpu().numpy(), exp)
     assert counters.cpu().tolist() == [int((exp > 0).sum()), int(exp.sum())]
+
+
+def _pack_bits(u):
+    u = np.asarray(u, dtype=np.uint32)
+    B, N = u.shape
+    w = (u.reshape(B, N // 32, 32) << np.arange(32, dtype=np.uint32)).sum(axis=2, dtype=np.uint64).astype(np.uint32)
+    return w.view(np.int32)
+
+
+def test_bp_readouts_match_compiled_bpr_fixture():
+    """BPr_128.c: polar_bp_readout_device reproduces the compiled program's decisions and its per-stage
+    read-out table E[6][n+1] on every fixture frame (iterMax 90, read-outs after 3, 6, 10, 20, 40, 80 iterations)."""
+    import torch
+    import polardecoding_amd as pa
+    g = load_golden("BPr_128")
+    iters, cp = int(g["iters"]), g["checkpoints"].tolist()
+    dec = pa.BP(128, 64, iterMax=iters)
+    F = len(g["sigma"])
+    ub = torch.from_numpy(_pack_bits(g["u"])).cuda()
+    for i in range(F):   # per frame: the fixture holds E frame by frame
+        y = torch.from_numpy(g["y"][i:i + 1].copy()).cuda()
+        E = torch.zeros(len(cp), 8, dtype=torch.int64, device="cuda")
+        out = torch.zeros(1, 4, dtype=torch.int32, device="cuda")
+        dec.bp_readout_device(y, ub[i:i + 1].contiguous(), cp, E, out_bits=out, sigma=float(g["sigma"][i]))
+        dec.synchronize()
+        assert np.array_equal(E.cpu().numpy(), g["E"][i]), i
+        assert np.array_equal(unpack_bits(out.cpu().numpy(), 128)[0], g["u_hat"][i]), i
+    # one launch over the frames of one noise level: the table is the sum
+    sel = np.nonzero(g["sigma"] == g["sigma"][0])[0]
+    y = torch.from_numpy(g["y"][sel].copy()).cuda()
+    E = torch.zeros(len(cp), 8, dtype=torch.int64, device="cuda")
+    dec.bp_readout_device(y, ub[sel].contiguous(), cp, E, sigma=float(g["sigma"][0]))
+    dec.synchronize()
+    assert np.array_equal(E.cpu().numpy(), g["E"][sel].sum(axis=0))
+
+
+def test_bp_readouts_vs_oracle_n512(oracle):
+    import torch
+    import polardecoding_amd as pa
+    N, K, iters, cp = 512, 256, 30, [1, 5, 30]
+    code = oracle.Code(N, K)
+    sim = oracle.Sim(31337)
+    sig = oracle.sigma_from_db(2.0)
+    us, ys = sim.frames(code, sig, 12)
+    llr = np.stack([oracle.llr_from_y(y, sig) for y in ys])
+    ref_uh, ref_E = oracle.bp_readout(code, llr, us, iters, cp)
+    dec = pa.BP(N, K, iterMax=iters)
+    E = torch.zeros(len(cp), code.n + 1, dtype=torch.int64, device="cuda")
+    out = torch.zeros(12, N // 32, dtype=torch.int32, device="cuda")
+    dec.bp_readout_device(torch.from_numpy(llr).cuda(), torch.from_numpy(_pack_bits(us)).cuda(), cp, E, out_bits=out)
+    dec.synchronize()
+    assert np.array_equal(E.cpu().numpy(), ref_E)
+    assert np.array_equal(unpack_bits(out.cpu().numpy(), N), ref_uh.astype(np.uint8))
+    # what the plain BP kernel decides after the same number of iterations
+    uh, _, _ = dec.decode_batch(llr)
+    assert np.array_equal(uh, ref_uh)

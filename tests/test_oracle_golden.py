@@ -89,6 +89,20 @@ def test_systematic_fixture_words_are_systematic_codewords(oracle):
     assert oracle.count_bit_errors(code, u, uh) == 1
 
 
+def test_oracle_bp_readouts_match_compiled_bpr(oracle):
+    """BPr_128.c (BP with per-stage read-outs): decisions and the per-frame E[6][n+1] of the fixture,
+    which the compiled program produced."""
+    g = load_golden("BPr_128")
+    code = oracle.Code(128, 64)
+    iters, cp = int(g["iters"]), g["checkpoints"].tolist()
+    assert (iters, cp) == (90, [3, 6, 10, 20, 40, 80])
+    for i in range(len(g["sigma"])):
+        llr = oracle.llr_from_y(g["y"][i], float(g["sigma"][i]))
+        uh, E = oracle.bp_readout(code, llr, g["u"][i].astype(np.int32), iters, cp)
+        assert np.array_equal(uh[0], g["u_hat"][i].astype(np.int32)), i
+        assert np.array_equal(E, g["E"][i]), i
+
+
 def test_crc6_dat_semantics():
     """CRC_6.dat format: 64x6 0/1 rows, row i = D^(6+i) mod (D^6+D^5+1), column j = coefficient
     of D^j.  The loader/generator lives in polardecoding_amd.crcfile; the expected rows are regenerated here."""
