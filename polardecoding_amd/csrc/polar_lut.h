@@ -181,15 +181,6 @@ __device__ __forceinline__ R chk_lut1(R a, R b, const Lut<R> &L)
 template <typename R>
 __device__ __forceinline__ R chk_lut(R a, R b, const Lut<R> &L)
 {
-#ifdef POLAR_DOUBLE_CHK  // timing experiment: marginal cost of one more CHK
-    {
-        const R s2 = b + a * R(1.0000001), d2 = a - b * R(1.0000001);
-        const int o2 = L.pick(s2, 0) + L.pick(d2, 16);
-        const R delta2 = *reinterpret_cast<const R *>(reinterpret_cast<const unsigned char *>(L.dlt) + o2);
-        const R r2 = xor_sign(minabs(s2, d2), a, b) + delta2;
-        __asm__ volatile("" ::"v"(r2));
-    }
-#endif
     const R s = a + b, d = a - b;
     const int os = L.pick(s, 0), od = L.pick(d, 16);
     const R delta = *reinterpret_cast<const R *>(reinterpret_cast<const unsigned char *>(L.dlt) + (os + od));

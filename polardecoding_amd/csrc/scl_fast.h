@@ -548,12 +548,6 @@ struct FastDec {
         uint32_t crcw = 0;
         if (CRC_ON && !frozen) crcw = crct[j];
         uint32_t bit = 0;
-#ifdef POLAR_DOUBLE_PHI
-        {
-            const R t2 = lut.tabv(lam * R(1.0000001));
-            __asm__ volatile("" ::"v"(t2));
-        }
-#endif
         const R tt = lut.tabv(lam);
         // PHI(.,0) = T + (lam < 0 ? |lam| : 0)  (SCL_1024.c:481-502); T + 0 is exact
         const R ph0 = tt + negmax(lam);
@@ -571,12 +565,6 @@ struct FastDec {
                 // phase 2 (SCL_1024.c:610-661)
                 POLAR_MARK("phase2_begin");
                 const R c0 = PM + ph0, c1 = PM + ph1;
-#ifdef POLAR_DOUBLE_RANK
-                {
-                    const uint32_t m2 = survivors(c1, c0);
-                    __asm__ volatile("" ::"s"(m2));
-                }
-#endif
                 const uint32_t mask = survivors(c0, c1);
                 POLAR_MARK("rank_end");
                 const uint32_t m0 = mask & 0xFFu, m1 = mask >> 8;
