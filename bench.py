@@ -6,7 +6,8 @@
 
 A "step" is one pass of the decode hot path (one kernel launch through the C ABI,
 polar_decode_device) over one batch of synthetic BPSK-AWGN frames per GPU, inputs (channel LLRs)
-already resident in HBM.  Frames are independent, so the batch shards across ranks with no
+already resident in HBM.  Steps alternate between two contexts / HIP streams per GPU, so the last,
+partly filled pass of one launch overlaps the first pass of the next (--one-stream turns that off).  Frames are independent, so the batch shards across ranks with no
 data-path collective (weak scaling: 2^17 frames per GPU per step = BASELINE config 4's 2^20 over
 8 GPUs); RCCL is used only for the final block/bit error counters and the max-over-ranks time.
 
@@ -78,6 +79,7 @@ def main():
     ap.add_argument("--snr", type=float, default=2.0)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-stream", action="store_true", help="all steps on one stream (no overlap of consecutive launches)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,8 +97,11 @@ def main():
     device = torch.device("cuda", local)
 
     dtype = pa.F64 if args.dtype == "f64" else pa.F32
-    dec = pa.CASCL(N, K, L=8, crc_taps=CRC, dtype=dtype, device=local)
-    dec.use_torch_stream()
+    # Two contexts, each with its own HIP stream, scratch and output buffer: step i runs on context i & 1, so the
+    # last, partly filled pass of one launch (131072 frames = 21.3 passes of the resident wavefronts) overlaps the
+    # first pass of the next instead of leaving CUs idle.  Every step is still one full decode of one batch.
+    decs = [pa.CASCL(N, K, L=8, crc_taps=CRC, dtype=dtype, device=local) for _ in range(1 if args.one_stream else 2)]
+    dec = decs[0]
     info = torch.tensor(pa.q_sequence(N)[N - (K + R):], device=device, dtype=torch.long)
 
     gen = torch.Generator(device=device)
@@ -104,12 +109,14 @@ def main():
     B = args.batch
     in_dtype = torch.float64 if args.dtype == "f64" else torch.float32
     batches = [make_batch(B, N, K, CRC, args.snr, info, device, gen, in_dtype) for _ in range(2)]
-    out_bits = torch.empty((B, N // 32), dtype=torch.int32, device=device)
+    outs = [torch.empty((B, N // 32), dtype=torch.int32, device=device) for _ in decs]
+    out_bits = outs[0]
     counters = torch.zeros(2, dtype=torch.int64, device=device)
+    torch.cuda.synchronize()   # the batches were made on torch's stream; the decoders run on their own
 
     def step(i):
         llr, _ = batches[i & 1]
-        dec.decode_device(llr, out_bits=out_bits)
+        decs[i % len(decs)].decode_device(llr, out_bits=outs[i % len(decs)])
 
     for i in range(args.warmup):
         step(i)
@@ -127,7 +134,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # FER of the last step (outside the timed region): device compare + RCCL sum of two counters
-    dec.count_errors_device(out_bits, batches[(args.steps - 1) & 1][1], counters)
+    last = args.steps - 1
+    decs[last % len(decs)].count_errors_device(outs[last % len(decs)], batches[last & 1][1], counters)
     torch.cuda.synchronize()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if dist:
@@ -188,14 +196,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"CASCL_1024_L8: N=1024 K=512 CRC-24C L=8, {B} frames/GPU/step "
                                    f"(2^20 over 8 GPUs), BPSK-AWGN Eb/N0={args.snr} dB, LLRs resident in HBM",
-                       "frames_per_gpu_per_step": B, "snr_db": args.snr, "parallelism": f"frames sharded x{world}"},
+                       "frames_per_gpu_per_step": B, "snr_db": args.snr, "parallelism": f"frames sharded x{world}",
+                       "streams_per_gpu": len(decs)},
             "fer": {"block_errors": blk, "bit_errors": bits, "frames": world * B,
                     "fer": blk / float(world * B)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": dec.kernel_name, "kernel_ms": ms_kernel,
                          "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
-                         "note": "path is VALU/LDS-bound, not HBM-bound (SURVEY.md 0.5); see DESIGN.md"},
+                         "note": "path is VALU/LDS-bound, not HBM-bound (SURVEY.md 0.5); see DESIGN.md.  kernel_ms is one "
+                                 "launch alone on its stream; with two streams consecutive steps overlap their partly "
+                                 "filled last pass, so ms_per_step can be below kernel_ms"},
         }
         if secondary:
             out["secondary"] = secondary
