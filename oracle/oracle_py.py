@@ -97,6 +97,8 @@ class Code:
         self.taps = list(crc_taps) if crc_taps else []
         self.r = max(self.taps) if self.taps else 0
         q = np.asarray(Q if Q is not None else q_for(N), dtype=np.int32)
+        if q.size != N:
+            raise ValueError(f"reliability order has {q.size} entries, need N = {N} (the 5G table stops at 1024: pass Q)")
         t = np.asarray(self.taps if self.taps else [0], dtype=np.int32)
         self._h = lib().po_code_create(N, K, self.r, _ip(t), len(self.taps), _ip(q))
         if not self._h:

@@ -196,7 +196,7 @@ int launch_sc_lanes(polar_ctx *c, const polar::SclParams &P)
 {
     using Cfg = polar::ScLanesCfg<R>;
     auto kern = polar::k_sc_lanes<R, IN>;
-    const size_t lds = Cfg::lds_bytes;
+    const size_t lds = Cfg::lds_bytes(P.N);
     const int threads = 64 * Cfg::WAVES;
     HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
@@ -217,7 +217,7 @@ int launch_sc_lanes(polar_ctx *c, const polar::SclParams &P)
 
 static bool sc_lanes_ok(const polar_ctx *c, size_t B)
 {
-    return c->cfg.algo == POLAR_ALGO_SC && !c->force_generic && c->cfg.N <= 1024 && B >= 64;
+    return c->cfg.algo == POLAR_ALGO_SC && !c->force_generic && c->cfg.N <= 2048 && B >= 64;
 }
 
 // the LDS / scratch split that measured best per arithmetic type (profiles/README.md); POLAR_BIG_SPLIT=35|46|57 overrides
@@ -699,7 +699,7 @@ int polar_create(const polar_cfg *cfg, polar_ctx **out)
             c->kernel_name = nm;
         }
     }
-    if (cfg->algo == POLAR_ALGO_SC && !c->force_generic && N <= 1024) {
+    if (cfg->algo == POLAR_ALGO_SC && !c->force_generic && N <= 2048) {
         snprintf(nm, sizeof nm, "k_sc_lanes<%s> (batches of 64+; k_scl_generic below)", cfg->dtype == POLAR_F32 ? "float" : "double");
         c->kernel_name = nm;
     }

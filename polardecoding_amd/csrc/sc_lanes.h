@@ -25,9 +25,9 @@ struct ScLanesCfg {
     static constexpr int WAVES = 4;
     static constexpr int TJ = 32;                                   // tile: 32 elements x 64 frames
     static constexpr size_t tile_bytes = sizeof(R) * TJ * 65;
-    static constexpr size_t bits_bytes = 4 * 64 * (32 + 16);        // blw[32][64] + curw[16][64]
-    static constexpr size_t wave_bytes = ((tile_bytes > bits_bytes ? tile_bytes : bits_bytes) + 15) & ~(size_t)15;
-    static constexpr size_t lds_bytes = wave_bytes * WAVES + Lut<R>::bytes;
+    static constexpr size_t bits_bytes(int N) { return 4 * 64 * (size_t)(N / 32 + N / 64); }   // blw[NW][64] + curw[NW/2][64]
+    static constexpr size_t wave_bytes(int N) { return ((tile_bytes > bits_bytes(N) ? tile_bytes : bits_bytes(N)) + 15) & ~(size_t)15; }
+    static constexpr size_t lds_bytes(int N) { return wave_bytes(N) * WAVES + Lut<R>::bytes; }
     static constexpr size_t scratch_bytes(int N) { return sizeof(R) * 2 * (size_t)N * 64; }
 };
 
@@ -76,11 +76,11 @@ __global__ __launch_bounds__(256) void k_sc_lanes(SclParams P)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *mine = smem + (size_t)wave * Cfg::wave_bytes;
+    unsigned char *mine = smem + (size_t)wave * Cfg::wave_bytes(N);
     R *tile = reinterpret_cast<R *>(mine);                       // [TJ][65] while a batch is loaded
-    uint32_t *blw = reinterpret_cast<uint32_t *>(mine);          // [32][64] afterwards: saved left partial sums
-    uint32_t *curw = blw + 32 * 64;                              // [16][64] working partial sums
-    unsigned char *lut_mem = smem + (size_t)Cfg::WAVES * Cfg::wave_bytes;
+    uint32_t *blw = reinterpret_cast<uint32_t *>(mine);          // [NW][64] afterwards: saved left partial sums
+    uint32_t *curw = blw + (size_t)NW * 64;                      // [NW/2][64] working partial sums
+    unsigned char *lut_mem = smem + (size_t)Cfg::WAVES * Cfg::wave_bytes(N);
     Lut<R>::build(lut_mem, threadIdx.x, blockDim.x);
     Lut<R> lut;
     lut.bind(lut_mem);

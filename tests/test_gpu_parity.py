@@ -124,19 +124,20 @@ def test_forced_spill_matches_golden(monkeypatch):
         assert np.array_equal(pm, g["pm"][sel])
 
 
-@pytest.mark.parametrize("N,K,B", [(1024, 512, 200), (128, 64, 333), (64, 20, 65), (32, 16, 130), (512, 400, 64), (1024, 40, 70)])
+@pytest.mark.parametrize("N,K,B", [(1024, 512, 200), (128, 64, 333), (64, 20, 65), (32, 16, 130), (512, 400, 64), (1024, 40, 70),
+                                   (2048, 1024, 66)])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_sc_one_codeword_per_lane_vs_oracle(N, K, B, dtype, oracle):
     """sc_lanes.h (B >= 64): 64 codewords per wavefront, frozen subtrees skipped -- same decisions as the oracle
     (= SC_128.c / SC_1024.c on the fixtures), ragged last batch, short and long codes, low and high rate."""
     import polardecoding_amd as pa
-    code = oracle.Code(N, K)
+    dec = pa.SCdecode(N, K, dtype=pa.F64 if dtype == "f64" else pa.F32)
+    code = oracle.Code(N, K) if N <= 1024 else _oracle_code_like(oracle, dec, N, K, None)
     sim = oracle.Sim(555 + N + K)
     sig = oracle.sigma_from_db(1.0 if K * 2 <= N else 3.0)
     us, ys = sim.frames(code, sig, B)
     llr = np.stack([oracle.llr_from_y(y, sig) for y in ys]).astype(np.float32).astype(np.float64)
     ref_uh, _, _ = oracle.decode(code, llr, "SC", dtype=dtype)
-    dec = pa.SCdecode(N, K, dtype=pa.F64 if dtype == "f64" else pa.F32)
     uh, pm, fl = dec.decode_batch(llr)
     assert np.array_equal(uh, ref_uh)
     # the y-input form (LLR formed in the kernel) on the same frames
