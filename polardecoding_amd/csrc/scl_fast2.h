@@ -486,6 +486,67 @@ struct Fast2Dec {
         POLAR_MARK("d2_end");
     }
 
+    // ---- the leading run of P all-frozen octets (leaves 0 .. 8P-1; 1 <= P <= 15), after octet_head(0) ----
+    // Nothing has been decided yet, so every partial sum below the first level-7 node is 0 and BOTH children of
+    // every node are known the moment the node is: f(x, y) and y + x.  The whole 128-leaf subtree is therefore
+    // evaluated as seven butterfly stages over one 128-element array per codeword (32 lanes, two butterflies per
+    // lane and stage) instead of octet by octet on eight replicated paths.  The values are those of the lazy
+    // recursion, operation for operation; the path metric adds PHI(lambda_j, 0) for j = 0 .. 8P-1 in that order
+    // (SCL_1024.c:601-604).  Afterwards the registers hold the nodes that contain leaf 8P at levels 4..6.
+    __device__ __forceinline__ void frozen_prefix(int P)
+    {
+        const int w32 = p * 4 + pos, j0 = 8 * P;
+        vm_drain();
+        const R *s7 = l7(0);   // every slot holds the same level-7 row while one path is alive
+        lds_fence();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) stg[w32 + 32 * k] = ld_sc(s7 + w32 + 32 * k);
+        lds_fence();
+#pragma unroll
+        for (int t = 6; t >= 0; --t) {
+            const int h = 1 << t;
+            int idx[2];
+            R x[2], y[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int b = w32 + 32 * i;
+                idx[i] = ((b >> t) << (t + 1)) | (b & (h - 1));
+                x[i] = stg[idx[i]];
+                y[i] = stg[idx[i] + h];
+            }
+            lds_fence();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                stg[idx[i]] = chk(x[i], y[i]);
+                stg[idx[i] + h] = y[i] + x[i];
+            }
+            lds_fence();
+            if (t >= 4) {   // node of level t that holds leaf j0: elements pos + 4r
+                const R *node = stg + ((j0 >> t) << t) + pos;
+                if (t == 6 && C::L6S) {
+                    R *o6 = l6s(p) + pos;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o6[4 * r] = node[4 * r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < h / 4; ++r) A[h / 4 + r] = node[4 * r];
+                }
+            }
+        }
+        // PHI(lambda_j, 0) of all 128 leaves, then the metric in leaf order
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const R lam = stg[w32 + 32 * k];
+            stg[128 + w32 + 32 * k] = lut.tabv(lam) + negmax(lam);
+        }
+        lds_fence();
+        R pm = PM;
+#pragma unroll 8
+        for (int j = 0; j < j0; ++j) pm += stg[128 + j];
+        PM = pm;
+        lds_fence();
+    }
+
     // ---- octets whose first seven leaves are frozen: breadth-first (all partner bits are 0) ----
     __device__ __forceinline__ void octet_frozen_prefix(int o, bool last_frozen)
     {
@@ -612,6 +673,14 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
     R *scr_wave = reinterpret_cast<R *>(P.scratch) + (size_t)wave_global * C::scratch_elems;
     s.scr = scr_wave + (size_t)c * C::scratch_cw;
 
+    // leading all-frozen octets (at most 15: the run must end inside the first 128-leaf subtree)
+    int lead = 0;
+    while (lead < 15 && ((frz[lead >> 2] >> (8 * (lead & 3))) & 0xFFu) == 0xFFu) ++lead;
+#ifdef POLAR_F2_NO_PREFIX
+    lead = 0;
+#endif
+    lead = __builtin_amdgcn_readfirstlane(lead);
+
     for (int pair = wave_global; 2 * pair < P.B; pair += waves_total) {
         const int frame_raw = 2 * pair + c;
         const bool live = frame_raw < P.B;
@@ -640,7 +709,16 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
         uint32_t fword = 0;
 
         STAMP(2);
-        for (int o = 0; o < N / 8; ++o) {
+        int o_first = 0;
+        if (lead > 0) {
+            s.octet_head(0);
+            STAMP(7);
+            s.frozen_prefix(lead);
+            STAMP(4);
+            o_first = lead;
+            fword = frz[o_first >> 2];
+        }
+        for (int o = o_first; o < N / 8; ++o) {
             if ((o & 3) == 0) fword = frz[o >> 2];
             s.octet_head(o);
             if (o == 0 || (o & 7) == 0) STAMP(7); else STAMP(3);
