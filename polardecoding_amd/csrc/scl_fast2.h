@@ -486,21 +486,39 @@ struct Fast2Dec {
         POLAR_MARK("d2_end");
     }
 
-    // ---- the leading run of P all-frozen octets (leaves 0 .. 8P-1; 1 <= P <= 15), after octet_head(0) ----
+    // ---- the leading run of P all-frozen octets (leaves 0 .. 8P-1; 1 <= P <= 15), instead of octets 0 .. P-1 ----
     // Nothing has been decided yet, so every partial sum below the first level-7 node is 0 and BOTH children of
     // every node are known the moment the node is: f(x, y) and y + x.  The whole 128-leaf subtree is therefore
     // evaluated as seven butterfly stages over one 128-element array per codeword (32 lanes, two butterflies per
     // lane and stage) instead of octet by octet on eight replicated paths.  The values are those of the lazy
     // recursion, operation for operation; the path metric adds PHI(lambda_j, 0) for j = 0 .. 8P-1 in that order
     // (SCL_1024.c:601-604).  Afterwards the registers hold the nodes that contain leaf 8P at levels 4..6.
+    // Levels 8 and 7 above it are computed once, by the codeword's 32 lanes together, into slot 0's scratch rows,
+    // and every slot points there (the eight slots are replicas of one path until the first information leaf).
     __device__ __forceinline__ void frozen_prefix(int P)
     {
         const int w32 = p * 4 + pos, j0 = 8 * P;
-        vm_drain();
-        const R *s7 = l7(0);   // every slot holds the same level-7 row while one path is alive
-        lds_fence();
+        vm_drain();   // the top-left level written by the root step
+        {
+            const R *tl = tls();
+            R *o8 = l8(0), *o7 = l7(0);
+            R v8[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) stg[w32 + 32 * k] = ld_sc(s7 + w32 + 32 * k);
+            for (int k = 0; k < 8; ++k) {
+                const int e = w32 + 32 * k;
+                v8[k] = chk(ld_sc(tl + e), ld_sc(tl + e + 256));
+                o8[e] = v8[k];
+            }
+            lds_fence();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const R v7 = chk(v8[k], v8[k + 4]);   // elements e and e + 128 of level 8
+                o7[w32 + 32 * k] = v7;
+                stg[w32 + 32 * k] = v7;
+            }
+            set_pa(8, 0);
+            set_pa(7, 0);
+        }
         lds_fence();
 #pragma unroll
         for (int t = 6; t >= 0; --t) {
@@ -711,8 +729,6 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
         STAMP(2);
         int o_first = 0;
         if (lead > 0) {
-            s.octet_head(0);
-            STAMP(7);
             s.frozen_prefix(lead);
             STAMP(4);
             o_first = lead;
