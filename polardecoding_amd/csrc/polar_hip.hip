@@ -59,6 +59,9 @@ struct polar_ctx {
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     Buf scratch;                          // k_scl_fast per-wave scratch
     Buf gen_llr, gen_u, gen_cnt;          // polar_fer_batch
+    Buf scratch_b;                        // second decode scratch: polar_fer_batch runs its two halves on two streams
+    hipStream_t stream_b = nullptr;
+    hipEvent_t ev_b = nullptr;
     std::string last_error;
     std::string kernel_name;
     bool force_generic = false;
@@ -718,8 +721,9 @@ void polar_destroy(polar_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
     for (Buf *b : {&c->in, &c->bits, &c->pm, &c->flags, &c->scratch, &c->gen_llr, &c->gen_u, &c->gen_cnt, &c->in2[0],
-                   &c->in2[1], &c->bits2[0], &c->bits2[1]})
+                   &c->in2[1], &c->bits2[0], &c->bits2[1], &c->scratch_b})
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 2; ++i) {
         if (c->h_bits[i]) (void)hipHostFree(c->h_bits[i]);
@@ -728,6 +732,8 @@ void polar_destroy(polar_ctx *c)
         if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->d_frozen) (void)hipFree(c->d_frozen);
     if (c->d_info) (void)hipFree(c->d_info);
     if (c->d_crc_tab) (void)hipFree(c->d_crc_tab);
@@ -923,13 +929,39 @@ int polar_fer_batch(polar_ctx *c, unsigned long long seed, unsigned long long fi
     if ((rc = ensure(c, c->bits, B * NW * 4))) return rc;
     if ((rc = ensure(c, c->gen_cnt, 16))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->gen_cnt.p, 0, 16, c->stream));
-    if ((rc = polar_generate_device(c, seed, first_frame, snr_db, B, c->gen_llr.p, f32 ? 1 : 0, 0, (uint32_t *)c->gen_u.p)))
-        return rc;
-    if ((rc = decode_device_impl(c, c->gen_llr.p, f32 ? 1 : 0, 0.0, B, (uint32_t *)c->bits.p, nullptr, nullptr, c->d_frozen)))
-        return rc;
-    if ((rc = polar_count_errors_device(c, (uint32_t *)c->bits.p, (uint32_t *)c->gen_u.p, B,
-                                        (unsigned long long *)c->gen_cnt.p, nullptr)))
-        return rc;
+    // Two halves on two streams (own decode scratch each): the generator of one half and the partly filled last
+    // pass of its decode overlap the other half's decode.  Frame i of the batch is the same frame either way
+    // (the generator is counter-based), and the two counters are atomics.
+    const size_t half = (B >= 32768) ? (B / 2 + 63) / 64 * 64 : B;
+    if (half < B && !c->stream_b) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
+    }
+    const size_t esz = f32 ? 4 : 8;
+    auto run_part = [&](size_t f0, size_t nf) -> int {
+        int r;
+        if ((r = polar_generate_device(c, seed, first_frame + f0, snr_db, nf, (char *)c->gen_llr.p + f0 * N * esz, f32 ? 1 : 0, 0,
+                                       (uint32_t *)c->gen_u.p + f0 * NW))) return r;
+        if ((r = decode_device_impl(c, (char *)c->gen_llr.p + f0 * N * esz, f32 ? 1 : 0, 0.0, nf, (uint32_t *)c->bits.p + f0 * NW,
+                                    nullptr, nullptr, c->d_frozen))) return r;
+        return polar_count_errors_device(c, (uint32_t *)c->bits.p + f0 * NW, (uint32_t *)c->gen_u.p + f0 * NW, nf,
+                                         (unsigned long long *)c->gen_cnt.p, nullptr);
+    };
+    if (half < B) {
+        // second half on stream_b, after the counters were cleared on the main stream
+        HIP_TRY(c, hipEventRecord(c->ev_b, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream_b, c->ev_b, 0));
+        std::swap(c->stream, c->stream_b);
+        std::swap(c->scratch, c->scratch_b);
+        rc = run_part(half, B - half);
+        hipError_t e = hipEventRecord(c->ev_b, c->stream);
+        std::swap(c->stream, c->stream_b);
+        std::swap(c->scratch, c->scratch_b);
+        if (rc) return rc;
+        HIP_TRY(c, e);
+    }
+    if ((rc = run_part(0, half))) return rc;
+    if (half < B) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_b, 0));
     unsigned long long h[2];
     HIP_TRY(c, hipMemcpyAsync(h, c->gen_cnt.p, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
