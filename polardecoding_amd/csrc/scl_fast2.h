@@ -94,10 +94,12 @@ struct Fast2Dec {
     __device__ __forceinline__ int pb(int t) const { return (ptr >> (3 * (NFA + t - 5))) & 7; }
     __device__ __forceinline__ void set_pb(int t, int v) { ptr = (ptr & ~(7u << (3 * (NFA + t - 5)))) | ((uint32_t)v << (3 * (NFA + t - 5))); }
     __device__ __forceinline__ R chk(R a, R b) const { return chk_lut<R>(a, b, lut); }
-#ifdef POLAR_F2_CHK1
-    __device__ __forceinline__ R chks(R a, R b) const { return chk_lut1<R>(a, b, lut); }  // serial chains
-#else
+    // the narrow levels inside an octet are serial chains: the one-round-trip table form (four more issue slots,
+    // one LDS latency less) measured +1.8 % there; POLAR_F2_CHK2 selects the compact form everywhere
+#ifdef POLAR_F2_CHK2
     __device__ __forceinline__ R chks(R a, R b) const { return chk_lut<R>(a, b, lut); }
+#else
+    __device__ __forceinline__ R chks(R a, R b) const { return chk_lut1<R>(a, b, lut); }
 #endif
     __device__ __forceinline__ R chv(int e) const
     {
