@@ -93,7 +93,13 @@ struct Fast2Dec {
     __device__ __forceinline__ void set_pa(int t, int v) { ptr = (ptr & ~(7u << (3 * (t - 4)))) | ((uint32_t)v << (3 * (t - 4))); }
     __device__ __forceinline__ int pb(int t) const { return (ptr >> (3 * (NFA + t - 5))) & 7; }
     __device__ __forceinline__ void set_pb(int t, int v) { ptr = (ptr & ~(7u << (3 * (NFA + t - 5)))) | ((uint32_t)v << (3 * (NFA + t - 5))); }
-    __device__ __forceinline__ R chk(R a, R b) const { return chk_lut<R>(a, b, lut); }
+    // wide steps: the compact two-round-trip form in f64; in f32 (4 waves/SIMD, cheaper VALU) the one-round-trip
+    // form measured +2.4 % there too
+    __device__ __forceinline__ R chk(R a, R b) const
+    {
+        if constexpr (sizeof(R) == 4) return chk_lut1<R>(a, b, lut);
+        else return chk_lut<R>(a, b, lut);
+    }
     // the narrow levels inside an octet are serial chains: the one-round-trip table form (four more issue slots,
     // one LDS latency less) measured +1.8 % there; POLAR_F2_CHK2 selects the compact form everywhere
 #ifdef POLAR_F2_CHK2
@@ -218,7 +224,10 @@ struct Fast2Dec {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) pre[m] = (m < nld) ? top_src(right, w32 + 32 * m, q + 1) : R(0);
             }
-#pragma unroll 1
+#ifndef POLAR_F2_TOP_UNROLL
+#define POLAR_F2_TOP_UNROLL 1
+#endif
+#pragma unroll POLAR_F2_TOP_UNROLL
             for (int i = 0; i < 4; ++i) {
                 const int rr = 4 * q + i;
                 const int e0 = pos + 4 * rr;
@@ -260,7 +269,10 @@ struct Fast2Dec {
         const R *s8 = l8(pa(8));
         const uint32_t *b7 = blw + pb(7) * NW + 4;  // beta_7: words 4..7
         R *o7 = l7(p), *o6 = l6s(p);
-        constexpr int CP = sizeof(R) == 8 ? 2 : 4;   // passes per chunk (4 loads each); f64: 8 in flight is the measured optimum
+#ifndef POLAR_F2_CP_F64
+#define POLAR_F2_CP_F64 2
+#endif
+        constexpr int CP = sizeof(R) == 8 ? POLAR_F2_CP_F64 : 4;   // passes per chunk (4 loads each); f64: 8 in flight is the measured optimum
         for (int q = 0; q < 16 / CP; ++q) {
             R *in = A;       // levels 2..5: dead here, recomputed by the f chain below
 #pragma unroll
