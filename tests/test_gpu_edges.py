@@ -106,3 +106,8 @@ def test_bench_under_torchrun_single_rank():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 1e5 and d["unit"] == "frames/s"
+    for key in ("metric", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline"):
+        assert key in d, key
+    assert d["scaling"] == "weak" and d["dtype"] == "f64" and d["roofline"]["bound"] == "hbm"
+    assert "workload" in d["config"] and "model" not in d["config"]
