@@ -126,6 +126,10 @@ int polar_count_errors_device(polar_ctx *ctx, const uint32_t *d_uhat_bits, const
 int polar_bp_readout_device(polar_ctx *ctx, const void *d_in, int in_is_f32, double sigma, size_t B,
                             const uint32_t *d_u_bits, const int *checkpoints, int ncp, unsigned long long *d_E,
                             uint32_t *d_uhat_bits);
+/* Host-buffer form, the shape of BPr_128.c's frame loop (:213): y [B][N] observations (sigma > 0) or LLRs (sigma = 0),
+ * u [B][N] sent bits (0/1 ints), E [ncp][n+1] accumulated (+=), u_hat [B][N] (may be NULL). */
+int polar_bp_readout_batch(polar_ctx *ctx, const double *in, double sigma, size_t B, const int *u,
+                           const int *checkpoints, int ncp, unsigned long long *E, int *u_hat);
 
 /* --- device-side transmit chain, throughput mode (the frame loop of main(), CASCL_1024_L8.c:245-292) -----------
  * Fills B frames: random payload -> CRC multiply by g(D) -> u[I[i]] -> x = u F^{(x)n} -> BPSK + AWGN at

@@ -871,6 +871,39 @@ int polar_bp_readout_device(polar_ctx *c, const void *d_in, int in_is_f32, doubl
     return in_is_f32 ? launch_bp_readout<double, float>(c, P) : launch_bp_readout<double, double>(c, P);
 }
 
+int polar_bp_readout_batch(polar_ctx *c, const double *in, double sigma, size_t B, const int *u, const int *checkpoints,
+                           int ncp, unsigned long long *E, int *u_hat)
+{
+    if (!c || !in || !u || !checkpoints || !E) return POLAR_EINVAL;
+    if (ncp < 1 || ncp > 8) return POLAR_EINVAL;
+    if (B == 0) return POLAR_OK;
+    const int N = c->cfg.N, NW = c->NW, n = c->n;
+    int rc;
+    if ((rc = ensure(c, c->in, B * N * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->bits, B * NW * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->gen_u, B * NW * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->gen_cnt, sizeof(unsigned long long) * 8 * (size_t)(n + 1)))) return rc;
+    std::vector<uint32_t> uw(B * (size_t)NW, 0u);
+    for (size_t b = 0; b < B; ++b)
+        for (int j = 0; j < N; ++j)
+            if (u[b * N + j]) uw[b * NW + (j >> 5)] |= 1u << (j & 31);
+    HIP_TRY(c, hipMemcpyAsync(c->in.p, in, B * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->gen_u.p, uw.data(), uw.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->gen_cnt.p, 0, sizeof(unsigned long long) * 8 * (size_t)(n + 1), c->stream));
+    rc = polar_bp_readout_device(c, c->in.p, 0, sigma, B, (const uint32_t *)c->gen_u.p, checkpoints, ncp,
+                                 (unsigned long long *)c->gen_cnt.p, (uint32_t *)c->bits.p);
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+    std::vector<unsigned long long> he((size_t)ncp * (n + 1));
+    std::vector<uint32_t> hb(u_hat ? B * (size_t)NW : 0);
+    HIP_TRY(c, hipMemcpyAsync(he.data(), c->gen_cnt.p, he.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    if (u_hat) HIP_TRY(c, hipMemcpyAsync(hb.data(), c->bits.p, hb.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < he.size(); ++i) E[i] += he[i];
+    if (u_hat)
+        for (size_t b = 0; b < B; ++b) unpack_words(hb.data() + b * NW, NW, u_hat + b * (size_t)N);
+    return POLAR_OK;
+}
+
 int polar_count_errors_device(polar_ctx *c, const uint32_t *d_uhat, const uint32_t *d_u, size_t B,
                               unsigned long long *d_counters, uint32_t *d_frame_err)
 {

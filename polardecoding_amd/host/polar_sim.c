@@ -119,7 +119,7 @@ static const int CRC6[] = {0, 5, 6};
 
 static void usage(void)
 {
-    fprintf(stderr, "usage: polar_sim --algo sc|bp|scl|cascl --N n --K k [--L l] [--crc 24c|6] [--sys] [--seed s] [--ble b]\n"
+    fprintf(stderr, "usage: polar_sim --algo sc|bp|bpr|scl|cascl --N n --K k [--L l] [--crc 24c|6] [--sys] [--seed s] [--ble b]\n"
                     "                 [--snr lo:hi:step] [--batch b] [--dtype f64|f32] [--bp-iters i] [--q file]\n");
     exit(2);
 }
@@ -127,7 +127,7 @@ static void usage(void)
 int main(int argc, char **argv)
 {
     int N = 1024, K = 512, L = 8, algo = POLAR_ALGO_CASCL, ble = 100, batch = 4096, dtype = POLAR_F64, bp_iters = 100;
-    int fast = 0, sys = 0;
+    int fast = 0, sys = 0, bpr = 0;
     uint64_t seed = 1024;
     double lo = 1.0, hi = 3.0, step = 0.5;
     const char *crc = NULL, *qfile = NULL;
@@ -135,6 +135,7 @@ int main(int argc, char **argv)
         const char *a = argv[i];
         const char *v = (i + 1 < argc) ? argv[i + 1] : NULL;
         if (!strcmp(a, "--algo") && v) {
+            if (!strcmp(v, "bpr")) { bpr = 1; v = "bp"; bp_iters = 90; }   /* BPr_128.c: iterMax 90 (:16) */
             algo = !strcmp(v, "sc") ? POLAR_ALGO_SC : !strcmp(v, "bp") ? POLAR_ALGO_BP
                  : !strcmp(v, "scl") ? POLAR_ALGO_SCL : !strcmp(v, "cascl") ? POLAR_ALGO_CASCL : -1;
             if (algo < 0) usage();
@@ -208,10 +209,16 @@ int main(int argc, char **argv)
         polar_destroy(ctx);
         return 0;
     }
+    static const int CP[6] = {3, 6, 10, 20, 40, 80};        /* BPr_128.c:18-23 */
+    int *ui = bpr ? (int *)malloc(sizeof(int) * (size_t)batch * N) : NULL;
+    int nlog = 0;
+    while ((1 << nlog) < N) nlog++;
     for (double db = lo; db <= hi + 1e-12; db += step) {
         const double sigma = pow(10, db / ((double)-20)); /* :226 */
         long run = 0, errbit = 0;
         int errblock = 0;
+        unsigned long long E[6 * 16];
+        memset(E, 0, sizeof E);
         while (errblock < ble) {
             for (int f = 0; f < batch; f++) {
                 make_frame(&g, &c, sigma, u + (size_t)f * N, y + (size_t)f * N);
@@ -230,9 +237,23 @@ int main(int argc, char **argv)
                 errblock += (e != 0);
                 run++;
             }
+            if (bpr) { /* read-outs of exactly the frames that count (BPr_128.c:417-565 runs inside BPr()) */
+                for (size_t k = 0; k < (size_t)f * N; k++) ui[k] = u[k];
+                rc = polar_bp_readout_batch(ctx, y, sigma, (size_t)f, ui, CP, 6, E, NULL);
+                if (rc) { fprintf(stderr, "readout: %s (%s)\n", polar_strerror(rc), polar_last_error(ctx)); return 1; }
+            }
             if (errblock >= ble) g = after[f - 1]; /* rewind to just after the frame that hit the stop rule */
         }
-        if (algo == POLAR_ALGO_SC || algo == POLAR_ALGO_BP) {
+        if (bpr) { /* BPr_128.c:227-258 */
+            printf("bSNR = %.2lf\terror block = %d\trun = %ld\t", db, errblock, run);
+            for (int q = 0; q < 6; q++) {
+                printf(q ? "After %2d iterations:\n" : "\nAfter %2d iterations:\n", CP[q]);
+                for (int i = 0; i <= nlog; i++) printf("%lf\t", (double)E[q * (nlog + 1) + i] / run);
+                printf("\n");
+            }
+            printf("BLER = %lfe-2\tBER = %lfe-2\tK * BER = %lf\n", (double)errblock * 100 / run,
+                   (double)errbit * 100 / K / run, (double)errbit / run);
+        } else if (algo == POLAR_ALGO_SC || algo == POLAR_ALGO_BP) {
             printf("bSNR = %.2lf\terror block = %d\trun = %ld\tBLER = %lf\n", db, errblock, run, (double)errblock / run);
             printf("Error bit = %ld\tBER = %lf\n", errbit, (double)errbit / K / run);
         } else if (c.sys) { /* CASCL_1024_sys.c:832-835 */

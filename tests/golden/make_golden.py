@@ -13,6 +13,9 @@ stores inputs + outputs:
     <name>.npz : sigma[F], y[F][N] f64, u[F][N] u8 (sent), u_hat[F][N] u8 (reference decision),
                  pm[F] f64 (metric of the chosen path; 0 for SC/BP)
 
+BPr_128_main_seed7.txt is the first 43 lines (three Eb/N0 points) of `oracle/_ref/BPr_128_main 7`, the compiled
+BPr_128.c main() with its time() seed pinned to 7 (4 minutes of CPU for all seven points).
+
 It also parses the reference's published fixed-seed logs (myResult_*.zip: data, not code) into
 published_runs.json: the known-answer run counts used by tests/test_oracle_kat.py.
 Only data is written here; no reference source text.

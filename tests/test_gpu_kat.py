@@ -62,3 +62,16 @@ def test_systematic_program_run_counts(oracle):
     got, text = run_sim(["--algo", "cascl", "--N", "1024", "--K", "512", "--L", "8", "--crc", "24c", "--sys",
                          "--snr", "1.0:1.5:0.5", "--seed", "4711", "--ble", "12", "--batch", "256"])
     assert got == exp, text
+
+
+def test_bpr_main_output_reproduced():
+    """BPr_128.c's whole main() (fixed seed 7, first three Eb/N0 points; tests/golden/BPr_128_main_seed7.txt is the
+    output of the compiled program: `oracle/_ref/BPr_128_main 7`): run counts, the six per-stage read-out rows per
+    point and the BLER / BER line, character for character, from `polar_sim --algo bpr`."""
+    assert os.path.exists(SIM), "polar_sim not built (run __graft_entry__.build())"
+    with open(os.path.join(GOLDEN, "BPr_128_main_seed7.txt")) as f:
+        exp = f.read()
+    out = subprocess.run([SIM, "--algo", "bpr", "--N", "128", "--K", "64", "--seed", "7", "--ble", "200",
+                          "--snr", "1.0:2.0:0.5", "--batch", "256"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout == exp, out.stdout[:3000]
