@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--one-stream", action="store_true", help="all steps on one stream (no overlap of consecutive launches)")
+    ap.add_argument("--streams", type=int, default=2, help="contexts / HIP streams the steps alternate over")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,7 +101,7 @@ def main():
     # Two contexts, each with its own HIP stream, scratch and output buffer: step i runs on context i & 1, so the
     # last, partly filled pass of one launch (131072 frames = 21.3 passes of the resident wavefronts) overlaps the
     # first pass of the next instead of leaving CUs idle.  Every step is still one full decode of one batch.
-    decs = [pa.CASCL(N, K, L=8, crc_taps=CRC, dtype=dtype, device=local) for _ in range(1 if args.one_stream else 2)]
+    decs = [pa.CASCL(N, K, L=8, crc_taps=CRC, dtype=dtype, device=local) for _ in range(1 if args.one_stream else args.streams)]
     dec = decs[0]
     info = torch.tensor(pa.q_sequence(N)[N - (K + R):], device=device, dtype=torch.long)
 
