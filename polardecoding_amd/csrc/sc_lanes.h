@@ -23,7 +23,13 @@ namespace polar {
 template <typename R>
 struct ScLanesCfg {
     static constexpr int WAVES = 4;
-    static constexpr int TJ = 32;                                   // tile: 32 elements x 64 frames
+#ifndef POLAR_SC_TJ
+#define POLAR_SC_TJ 32
+#endif
+#ifndef POLAR_SC_WAVES_PER_SIMD
+#define POLAR_SC_WAVES_PER_SIMD 2
+#endif
+    static constexpr int TJ = POLAR_SC_TJ;                          // tile: TJ elements x 64 frames
     static constexpr size_t tile_bytes = sizeof(R) * TJ * 65;
     static constexpr size_t bits_bytes(int N) { return 4 * 64 * (size_t)(N / 32 + N / 64); }   // blw[NW][64] + curw[NW/2][64]
     static constexpr size_t wave_bytes(int N) { return ((tile_bytes > bits_bytes(N) ? tile_bytes : bits_bytes(N)) + 15) & ~(size_t)15; }
@@ -69,7 +75,7 @@ struct ScLanes {
 };
 
 template <typename R, typename IN>
-__global__ __launch_bounds__(256) void k_sc_lanes(SclParams P)
+__global__ __launch_bounds__(256, POLAR_SC_WAVES_PER_SIMD) void k_sc_lanes(SclParams P)
 {
     using Cfg = ScLanesCfg<R>;
     const int N = P.N, n = P.n, NW = N >> 5;
@@ -97,15 +103,16 @@ __global__ __launch_bounds__(256) void k_sc_lanes(SclParams P)
         // ---- channel LLRs (SC_128.c:416-420), transposed to [element][lane] through the LDS tile ----
         for (int j0 = 0; j0 < N; j0 += Cfg::TJ) {
             sync();
+            constexpr int FP = 64 / Cfg::TJ;   // frames per pass
 #pragma unroll 4
-            for (int f = 0; f < 64; f += 2) {
-                const int fr = frame0 + f + (lane >> 5);
+            for (int f = 0; f < 64; f += FP) {
+                const int fr = frame0 + f + lane / Cfg::TJ;
                 double v = 0.0;
                 if (fr < P.B) {
-                    v = (double)reinterpret_cast<const IN *>(P.in)[(size_t)fr * N + j0 + (lane & 31)];
+                    v = (double)reinterpret_cast<const IN *>(P.in)[(size_t)fr * N + j0 + (lane % Cfg::TJ)];
                     if (P.sigma > 0) v = llr_from_y(v, P.sigma);
                 }
-                tile[(lane & 31) * 65 + f + (lane >> 5)] = (R)v;
+                tile[(lane % Cfg::TJ) * 65 + f + lane / Cfg::TJ] = (R)v;
             }
             sync();
 #pragma unroll 4
