@@ -52,3 +52,30 @@ def fer_point(decode_and_count, total_frames, rank=0, world=1, dist=None, device
     c = torch.tensor([int(blk), int(bits)], dtype=torch.int64, device=device)
     allreduce_counters(c, dist)
     return int(c[0].item()), int(c[1].item()), total_frames
+
+
+def gather_frame_errors(frame_err_local, total_frames, rank=0, world=1, dist=None):
+    """Per-frame bit-error counts of this rank's contiguous shard (frame_shard order) -> the counts of all
+    `total_frames` frames in frame order on every rank.  This is the one extra exchange the exact sequential stop
+    rule needs when a batch is spread over GPUs (4 bytes per frame); shards differ by at most one frame,
+    so they are padded to a common length for all_gather."""
+    fe = torch.as_tensor(frame_err_local).to(torch.int32).flatten()
+    if dist is None or not dist.is_initialized() or world == 1:
+        return fe
+    base, rem = divmod(total_frames, world)
+    width = base + (1 if rem else 0)
+    pad = torch.zeros(width, dtype=torch.int32, device=fe.device)
+    pad[:fe.numel()] = fe
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    out = []
+    for r in range(world):
+        _, cnt = frame_shard(total_frames, r, world)
+        out.append(parts[r][:cnt])
+    return torch.cat(out)
+
+
+def sequential_stop_cut_sharded(frame_err_local, total_frames, ble, rank=0, world=1, dist=None):
+    """sequential_stop_cut over a batch that was decoded in shards: same (run, block_errors, bit_errors) on every
+    rank as one process decoding the whole batch would get."""
+    return sequential_stop_cut(gather_frame_errors(frame_err_local, total_frames, rank, world, dist), ble)

@@ -93,7 +93,7 @@ import os, sys
 sys.path.insert(0, {repo!r})
 import numpy as np, torch, torch.distributed as dist
 from oracle import oracle_py as O            # checker standing in for the GPU decoder in this CPU test
-from polardecoding_amd.montecarlo import fer_point
+from polardecoding_amd.montecarlo import fer_point, frame_shard, sequential_stop_cut_sharded
 rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 code = O.Code(128, 64, O.CRC6_TAPS)
@@ -107,8 +107,16 @@ def dec(start, count):
         blk += e > 0; bits += e
     return blk, bits
 res = fer_point(dec, 96, rank, world, dist)
+# exact sequential stop rule over a sharded batch of 95 frames (uneven shards): per-frame error counts gathered in frame order
+start, count = frame_shard(95, rank, world)
+fe = []
+for i in range(start, start + count):
+    uh, _, _ = O.decode(code, O.llr_from_y(ys[i], sig), "CASCL", L=8)
+    fe.append(O.count_bit_errors(code, us[i], uh))
+cut = sequential_stop_cut_sharded(fe, 95, 5, rank, world, dist)
 if rank == 0:
     print("RESULT", res[0], res[1], res[2])
+print("CUT", rank, *(cut if cut else (-1, -1, -1)))
 dist.destroy_process_group()
 """
 
@@ -134,3 +142,14 @@ def test_two_rank_gloo_matches_single_process(oracle, tmp_path):
         assert p.returncode == 0, e[-2000:]
     line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT")][0].split()
     assert [int(x) for x in line[1:]] == [blk, bits, 96]
+    # the cut at the 5th block error, as one process sees it
+    from polardecoding_amd.montecarlo import sequential_stop_cut
+    fe = []
+    for i in range(95):
+        uh, _, _ = oracle.decode(code, oracle.llr_from_y(ys[i], sig), "CASCL", L=8)
+        fe.append(oracle.count_bit_errors(code, us[i], uh))
+    want = sequential_stop_cut(fe, 5)
+    assert want is not None
+    for o, _ in outs:
+        cl = [l for l in o.splitlines() if l.startswith("CUT")][0].split()
+        assert tuple(int(x) for x in cl[2:]) == want
