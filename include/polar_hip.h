@@ -53,8 +53,8 @@ typedef struct polar_ctx polar_ctx;
 /* Replaces the reference's compile-time configuration (#define N K n L r iterMax, CASCL_1024_L8.c:16-21;
  * the Q-table derived I[] / inI[], :209-217; the CRC taps written inline at :253-265 and :581-593). */
 typedef struct polar_cfg {
-    int N;                 /* block length, power of two, 32..4096 (BP: <= 1024, a codeword's messages must fit
-                              one CU's LDS; larger N returns POLAR_ENOKERNEL at the first decode)            */
+    int N;                 /* block length, power of two, 32..4096 (BP above 1024: the messages no longer fit one
+                              CU's LDS and live in global scratch -- complete, not fast)                     */
     int K;                 /* payload bits                                                               */
     int crc_r;             /* CRC length r (0 = none)                                                    */
     const int *crc_taps;   /* exponents of g(D) incl. 0 and r, e.g. {0,5,6} (CASCL_128.c:212-214)        */

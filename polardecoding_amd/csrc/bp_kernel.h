@@ -275,6 +275,76 @@ constexpr size_t bp_readout_lds_bytes(int N, int n)
     return sizeof(R) * 2 * (size_t)(n + 1) * N + (size_t)N + 4 * (size_t)(N / 32) + 16 + 16 + Lut<R>::bytes;
 }
 
+// ---- BP for block lengths whose messages do not fit one CU's LDS (N > 1024): same schedule, rows in a per-workgroup
+// slice of a global scratch buffer (plain stores, sc1 loads, a workgroup barrier after every stage).  Correct and
+// complete rather than fast: no reference program and no BASELINE config uses BP above N = 1024.
+template <typename R, typename IN>
+__global__ __launch_bounds__(512) void k_bp_global(BpParams P, R *scratch)
+{
+    const int N = P.N, n = P.n, NW = N >> 5;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *obits = reinterpret_cast<uint32_t *>(smem);   // [NW]
+    unsigned char *lut_mem = reinterpret_cast<unsigned char *>(obits + NW);
+    lut_mem += (16 - (reinterpret_cast<uintptr_t>(lut_mem) & 15)) & 15;
+    Lut<R>::build(lut_mem, tid, nt);
+    Lut<R> lut;
+    lut.bind(lut_mem);
+    R *lm = scratch + (size_t)blockIdx.x * 2 * (size_t)(n + 1) * N;   // l[0..n][N]
+    R *rm = lm + (size_t)(n + 1) * N;                                  // r[0..n][N]
+    auto ld = [](const R *q) -> R { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    __syncthreads();
+#define LM(i, j) lm[(size_t)(i) * N + (j)]
+#define RM(i, j) rm[(size_t)(i) * N + (j)]
+    for (int frame = blockIdx.x; frame < P.B; frame += gridDim.x) {
+        const IN *src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
+        for (int i = tid; i < (n + 1) * N; i += nt) {
+            lm[i] = R(0);
+            rm[i] = R(0);
+        }
+        __syncthreads();
+        for (int j = tid; j < N; j += nt) {
+            double v = (double)src[j];
+            if (P.sigma > 0) v = llr_from_y(v, P.sigma);
+            LM(n, j) = (R)v;
+            RM(0, j) = ((P.frozen[j >> 5] >> (j & 31)) & 1) ? R(999) : R(0);
+        }
+        for (int i = tid; i < NW; i += nt) obits[i] = 0;
+        __syncthreads();
+        for (int it = 0; it < P.iters; ++it) {
+            for (int i = 0; i < n; ++i) {
+                const int s = 1 << i;
+                for (int b = tid; b < N / 2; b += nt) {
+                    const int j = ((b >> i) << (i + 1)) | (b & (s - 1));
+                    const R r0 = ld(&RM(i, j)), r1 = ld(&RM(i, j + s)), l0 = ld(&LM(i + 1, j)), l1 = ld(&LM(i + 1, j + s));
+                    RM(i + 1, j) = chk_lut<R>(r0, l1 + r1, lut);
+                    RM(i + 1, j + s) = r1 + chk_lut<R>(r0, l0, lut);
+                }
+                __syncthreads();
+            }
+            for (int i = n - 1; i >= 0; --i) {
+                const int s = 1 << i;
+                for (int b = tid; b < N / 2; b += nt) {
+                    const int j = ((b >> i) << (i + 1)) | (b & (s - 1));
+                    const R r0 = ld(&RM(i, j)), r1 = ld(&RM(i, j + s)), l0 = ld(&LM(i + 1, j)), l1 = ld(&LM(i + 1, j + s));
+                    LM(i, j) = chk_lut<R>(l0, l1 + r1, lut);
+                    LM(i, j + s) = l1 + chk_lut<R>(r0, l0, lut);
+                }
+                __syncthreads();
+            }
+        }
+        for (int j = tid; j < N; j += nt) {
+            const bool fr = (P.frozen[j >> 5] >> (j & 31)) & 1;
+            if (!fr && !(ld(&LM(0, j)) + ld(&RM(0, j)) >= R(0))) atomicOr(&obits[j >> 5], 1u << (j & 31));
+        }
+        __syncthreads();
+        for (int i = tid; i < NW; i += nt) P.out_bits[(size_t)frame * NW + i] = obits[i];
+        __syncthreads();
+    }
+#undef LM
+#undef RM
+}
+
 // ---- error accounting (main()'s compare loop, CASCL_1024_L8.c:296-305) -------------------------------
 // One thread per frame word would be enough; one wave per frame keeps it trivially coalesced.
 struct CountParams {

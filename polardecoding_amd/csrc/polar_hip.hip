@@ -340,7 +340,17 @@ int launch_bp(polar_ctx *c, const polar::BpParams &P)
 {
     auto kern = polar::k_bp<R, IN>;
     const size_t lds = polar::bp_lds_bytes<R>(P.N, P.n);
-    if (lds > 160 * 1024) return POLAR_ENOKERNEL;
+    if (lds > 160 * 1024) {   // messages do not fit a CU's LDS: rows in global scratch
+        auto kg = polar::k_bp_global<R, IN>;
+        const size_t lds_g = 4 * (size_t)(P.N / 32) + 16 + polar::Lut<R>::bytes;
+        int grid = (int)std::min<long long>((long long)P.B, (long long)2 * c->num_cu);
+        if (grid < 1) grid = 1;
+        int rc = ensure(c, c->scratch, sizeof(R) * 2 * (size_t)(P.n + 1) * P.N * (size_t)grid);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kg, dim3(grid), dim3(512), lds_g, c->stream, P, reinterpret_cast<R *>(c->scratch.p));
+        HIP_TRY(c, hipGetLastError());
+        return POLAR_OK;
+    }
     HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
     const int threads = std::max(64, std::min(512, P.N / 2));

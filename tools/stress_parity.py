@@ -57,7 +57,7 @@ for dtype in ("f64", "f32"):
             for B in (int(rng.integers(1, 63)), int(rng.integers(64, 200))):
                 check(f"SC N={N} K={K} {dtype}", dec, code, "SC", 1, B, 2.0 if K * 2 <= N else 5.0, dtype)
     # BP
-    for N, it in ((32, 7), (128, 20), (512, 11), (1024, 6)):   # BP keeps a codeword in one CU's LDS: N <= 1024
+    for N, it in ((32, 7), (128, 20), (512, 11), (1024, 6), (2048, 4), (4096, 3)):   # above 1024: rows in global scratch
         K = N // 2
         dec = pa.BP(N, K, iterMax=it, dtype=dt)
         code = O.Code(N, K, None, Q=q_of(dec, N, K, None))
