@@ -215,6 +215,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.snr)
         print(json.dumps(out), flush=True)
     if dist:
+        dist.barrier()   # rank 0 still measures the kernel-level figures after the timed region: leave together
         dist.destroy_process_group()
 
 
