@@ -25,6 +25,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
+#include <unistd.h>
 
 #include "polar_hip.h"
 
@@ -58,18 +60,6 @@ static double ranq1(gen_state *g) /* SCL_1024.c:295-309 */
     return (double)(g->ranv * 2685821657736338717ULL) * 5.42101086242752217E-20;
 }
 
-static void normal_pair(gen_state *g, double sigma, double *n1, double *n2) /* SCL_1024.c:312-326 */
-{
-    double x1, x2, s;
-    do {
-        x1 = 2 * ranq1(g) - 1;
-        x2 = 2 * ranq1(g) - 1;
-        s = x1 * x1 + x2 * x2;
-    } while (s >= 1.0);
-    *n1 = sigma * x1 * sqrt(-2 * log(s) / s);
-    *n2 = sigma * x2 * sqrt(-2 * log(s) / s);
-}
-
 typedef struct {
     int N, K, r, A, ntaps;
     int taps[32];
@@ -77,16 +67,37 @@ typedef struct {
     int sys; /* --sys: systematic CRC encoding and K-bit error metric (CASCL_1024_sys.c) */
 } code_t;
 
-static void make_frame(gen_state *g, const code_t *c, double sigma, unsigned char *u, double *y)
+/* The reference's generator is one sequential stream, but only its cheap part is: the xorshift steps and the
+ * rejection test of the polar method (SCL_1024.c:295-326).  draw_frame() runs that part in frame order and keeps the
+ * accepted (x1, x2, s) of every pair; finish_frame() -- payload, CRC, encoding and the log/sqrt of the noise, with the
+ * reference's own expressions -- is then done for the frames of a batch in parallel.  Same bits as doing it all in order. */
+typedef struct { double x1, x2, s; } pair_t;
+
+static void draw_frame(gen_state *g, const code_t *c, pair_t *pr, int *m_of_frame)
+{
+    *m_of_frame = g->m;
+    for (int i = 0; i < c->N / 2; i++) { /* SCL_1024.c:312-326, the loop of normal() */
+        double x1, x2, s;
+        do {
+            x1 = 2 * ranq1(g) - 1;
+            x2 = 2 * ranq1(g) - 1;
+            s = x1 * x1 + x2 * x2;
+        } while (s >= 1.0);
+        pr[i].x1 = x1; pr[i].x2 = x2; pr[i].s = s;
+    }
+    g->m += c->K % 63; /* :273-274 */
+    if (g->m >= 63) g->m -= 63;
+}
+
+static void finish_frame(const code_t *c, int m, const pair_t *pr, double sigma, unsigned char *u, double *y)
 {
     const int N = c->N;
-    static int w[4096 + 64];
-    static unsigned char x[4096];
+    int w[4096 + 64], d[4096 + 64];
+    unsigned char x[4096];
     for (int i = 0; i < c->A; i++) w[i] = 0;
     if (c->sys && c->r > 0) {
         /* CASCL_1024_sys.c:776-789: w[r..A) = payload, w[0..r) = D^r v(D) mod g (sum of the generator rows) */
-        for (int i = 0; i < c->K; i++) w[c->r + i] = PN[(g->m + i) % 63];
-        static int d[4096 + 64];
+        for (int i = 0; i < c->K; i++) w[c->r + i] = PN[(m + i) % 63];
         for (int i = 0; i < c->A; i++) d[i] = (i < c->r) ? 0 : w[i];
         for (int i = c->A - 1; i >= c->r; i--)
             if (d[i])
@@ -94,7 +105,7 @@ static void make_frame(gen_state *g, const code_t *c, double sigma, unsigned cha
         for (int i = 0; i < c->r; i++) w[i] = d[i];
     } else
     for (int i = 0; i < c->K; i++)
-        if (PN[(g->m + i) % 63]) {
+        if (PN[(m + i) % 63]) {
             if (c->r == 0) w[i] ^= 1;
             else for (int t = 0; t < c->ntaps; t++) w[i + c->taps[t]] ^= 1; /* CASCL_1024_L8.c:251-266 */
         }
@@ -104,14 +115,50 @@ static void make_frame(gen_state *g, const code_t *c, double sigma, unsigned cha
     for (int s = 1; s < N; s <<= 1)
         for (int j = 0; j < N; j++)
             if (!(j & s)) x[j] ^= x[j + s];
-    for (int i = 0; i < N; i += 2) { /* SCL_1024.c:253-261 */
-        double n1, n2;
-        normal_pair(g, sigma, &n1, &n2);
+    for (int i = 0; i < N; i += 2) { /* SCL_1024.c:253-261 with :322-323 */
+        const double x1 = pr[i / 2].x1, x2 = pr[i / 2].x2, s = pr[i / 2].s;
+        const double n1 = sigma * x1 * sqrt(-2 * log(s) / s);
+        const double n2 = sigma * x2 * sqrt(-2 * log(s) / s);
         y[i] = x[i] ? -1 + n1 : 1 + n1;
         y[i + 1] = x[i + 1] ? -1 + n2 : 1 + n2;
     }
-    g->m += c->K % 63; /* :273-274 */
-    if (g->m >= 63) g->m -= 63;
+}
+
+typedef struct {
+    const code_t *c; const int *m; const pair_t *pr; double sigma; unsigned char *u; double *y;
+    int f0, f1;
+} job_t;
+
+static void *finish_job(void *arg)
+{
+    const job_t *j = (const job_t *)arg;
+    const int N = j->c->N;
+    for (int f = j->f0; f < j->f1; f++)
+        finish_frame(j->c, j->m[f], j->pr + (size_t)f * (N / 2), j->sigma, j->u + (size_t)f * N, j->y + (size_t)f * N);
+    return NULL;
+}
+
+/* a batch of frames in the reference's order; after[f] = generator state just after frame f */
+static void make_batch(gen_state *g, const code_t *c, double sigma, int batch, unsigned char *u, double *y, gen_state *after,
+                       pair_t *pr, int *mf)
+{
+    const int N = c->N;
+    for (int f = 0; f < batch; f++) {
+        draw_frame(g, c, pr + (size_t)f * (N / 2), &mf[f]);
+        after[f] = *g;
+    }
+    long nt = sysconf(_SC_NPROCESSORS_ONLN);
+    if (nt > 16) nt = 16;
+    if (nt > batch / 64) nt = batch / 64;
+    if (nt < 1) nt = 1;
+    pthread_t th[16];
+    job_t jobs[16];
+    for (long t = 0; t < nt; t++) {
+        jobs[t] = (job_t){c, mf, pr, sigma, u, y, (int)((long)batch * t / nt), (int)((long)batch * (t + 1) / nt)};
+        if (t + 1 < nt) pthread_create(&th[t], NULL, finish_job, &jobs[t]);
+    }
+    finish_job(&jobs[nt - 1]);
+    for (long t = 0; t + 1 < nt; t++) pthread_join(th[t], NULL);
 }
 
 static const int CRC24C[] = {0, 1, 2, 4, 8, 12, 13, 15, 17, 20, 21, 23, 24};
@@ -191,6 +238,9 @@ int main(int argc, char **argv)
     unsigned char *u = (unsigned char *)malloc((size_t)batch * N);
     int *uh = (int *)malloc(sizeof(int) * (size_t)batch * N);
     gen_state *after = (gen_state *)malloc(sizeof(gen_state) * (size_t)batch);
+    pair_t *pairs = (pair_t *)malloc(sizeof(pair_t) * (size_t)batch * (N / 2));
+    int *mf = (int *)malloc(sizeof(int) * (size_t)batch);
+    if (!y || !u || !uh || !after || !pairs || !mf) { fprintf(stderr, "out of memory\n"); return 1; }
     printf("SEED = %llu\n", (unsigned long long)seed);
     if (fast) {
         unsigned long long first = 0;
@@ -220,10 +270,7 @@ int main(int argc, char **argv)
         unsigned long long E[6 * 16];
         memset(E, 0, sizeof E);
         while (errblock < ble) {
-            for (int f = 0; f < batch; f++) {
-                make_frame(&g, &c, sigma, u + (size_t)f * N, y + (size_t)f * N);
-                after[f] = g;
-            }
+            make_batch(&g, &c, sigma, batch, u, y, after, pairs, mf);
             rc = polar_decode_batch_y(ctx, y, sigma, (size_t)batch, uh, NULL, NULL);
             if (rc) { fprintf(stderr, "decode: %s (%s)\n", polar_strerror(rc), polar_last_error(ctx)); return 1; }
             int f;
