@@ -205,8 +205,9 @@ __global__ __launch_bounds__(256) void k_scl_big(SclParams P)
             if (p < act) {
                 const int ss = ptr_get<LOGL>(ptrA, t + 1);
                 R *out = lowA + p * LOW + h;
-                uint32_t wv = bl0 >> h;  // t < 5: bit 2^t + e of the register word
-                if (gstep && t == 5) wv = blw[ptr_get<LOGL>(ptrB, 5) * WL + 1];
+                uint32_t wv = 0;
+                if constexpr (t < 5) wv = bl0 >> h;  // bit 2^t + e of the register word
+                else if (gstep) wv = blw[ptr_get<LOGL>(ptrB, 5) * WL + 1];
                 if (t == TL) {
                     const R *src = hiA + (size_t)ss * N + 2 * h;
                     constexpr int PER = h / S;                             // elements per lane
