@@ -76,6 +76,14 @@ def lib():
         L.po_run_sweep.argtypes = [C.POINTER(_Code), C.c_int, C.c_int, C.c_int, C.c_uint64, dp, C.c_int,
                                    C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]
         L.po_count_bit_errors.argtypes = [C.POINTER(_Code), ip, ip]
+        L.po_lit_create.restype = C.c_void_p
+        L.po_lit_create.argtypes = [C.POINTER(_Code), C.c_int]
+        L.po_lit_destroy.argtypes = [C.c_void_p]
+        L.po_lit_reset.argtypes = [C.c_void_p]
+        L.po_lit_poison.argtypes = [C.c_void_p, C.c_uint64]
+        L.po_lit_decode.argtypes = [C.c_void_p, dp, C.c_int, ip, dp]
+        L.po_lit_diag.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.c_int]
+        L.po_lit_path_metrics.argtypes = [C.c_void_p, dp]
         _lib = L
     return _lib
 
@@ -129,8 +137,10 @@ def llr_from_y(y, sigma):
     return out
 
 
-def decode(code, llr, algo, L=8, bp_iters=100, dtype="f64"):
-    """Decode one frame or a [B][N] batch.  Returns (u_hat [B][N] int32, pm [B], ties [B])."""
+def decode(code, llr, algo, L=8, bp_iters=100, dtype="f64", stats=None):
+    """Decode one frame or a [B][N] batch.  Returns (u_hat [B][N] int32, pm [B], ties [B]).
+    stats (optional int32 [B][2], list decoders): per frame, leaves where the 32-bit ranking keys are not enough,
+    leaves with three or more equal candidates (po_scl_last_stats)."""
     L_ = lib()
     f32 = dtype == "f32"
     llr = np.ascontiguousarray(llr, dtype=np.float32 if f32 else np.float64)
@@ -152,11 +162,55 @@ def decode(code, llr, algo, L=8, bp_iters=100, dtype="f64"):
             fn = L_.po_scl_decode_f32 if f32 else L_.po_scl_decode_f64
             rc = fn(code._h, lp, L, 1 if algo == "CASCL" else 0, up,
                     pm[b:].ctypes.data_as(rp), ties[b:].ctypes.data_as(C.POINTER(C.c_int)))
+            if stats is not None:
+                L_.po_scl_last_stats(stats.reshape(-1, 2)[b].ctypes.data_as(C.POINTER(C.c_int)))
         if rc != 0:
             raise RuntimeError(f"oracle decode failed rc={rc}")
     if single:
         return uh[0], pm[0], ties[0]
     return uh, pm, ties
+
+
+class Literal:
+    """The reference's list decoder WITH its persistent node records (oracle/polar_oracle_literal.c): what
+    SCLdecode / CASCL do frame after frame, including after a median tie.  decode() -> (u_hat, pm, diag[3]) with
+    diag = counts of "Oops!", "Wrong propagation order!", "Error!" for that frame."""
+
+    def __init__(self, code, L=8, crc=False):
+        self.code, self.L, self.crc = code, L, bool(crc)
+        self._h = lib().po_lit_create(code._h, L)
+        if not self._h:
+            raise ValueError("bad list size")
+
+    def __del__(self):
+        try:
+            lib().po_lit_destroy(self._h)
+        except Exception:
+            pass
+
+    def reset(self):
+        lib().po_lit_reset(self._h)
+
+    def poison(self, seed):
+        """arbitrary leftovers in every record a frame does not initialise (stands for an unknown history)"""
+        lib().po_lit_poison(self._h, seed)
+
+    def decode(self, llr):
+        llr = np.ascontiguousarray(llr, dtype=np.float64)
+        uh = np.zeros(self.code.N, dtype=np.int32)
+        pm = C.c_double(0)
+        rc = lib().po_lit_decode(self._h, _dp(llr), 1 if self.crc else 0, _ip(uh), C.byref(pm))
+        d = (C.c_long * 3)()
+        lib().po_lit_diag(self._h, d, 1)
+        if rc not in (0, -3, -5):
+            raise RuntimeError(f"po_lit_decode rc={rc}")
+        self.last_rc = rc   # -5: the reference would never return from this frame (Partition, SCL_1024.c:518-544)
+        return uh, pm.value, list(d)
+
+    def path_metrics(self):
+        out = np.zeros(self.L)
+        lib().po_lit_path_metrics(self._h, _dp(out))
+        return out
 
 
 class Sim:
@@ -255,6 +309,24 @@ class Ref:
         self.l.ref_time_decode.argtypes = [C.POINTER(C.c_double), C.c_double, C.c_long, C.POINTER(C.c_int)]
         self.l.ref_init()
         self.N = self.l.ref_block_length()
+        self.L = self.l.ref_list_size()
+        self.l.ref_diag.argtypes = [C.POINTER(C.c_long), C.c_int]
+
+    def diag(self, reset=True):
+        """counts of "Oops!" (SCL_1024.c:622), "Wrong propagation order!" (:418), "Error!" (:651) printed since the last reset"""
+        d = (C.c_long * 3)()
+        self.l.ref_diag(d, 1 if reset else 0)
+        return list(d)
+
+    def reset_state(self):
+        """list decoders only: node records back to their calloc() state (what the decoder does after a median
+        tie depends on what earlier frames left in them)"""
+        self.l.ref_reset_state()
+
+    def path_metrics(self):
+        out = np.zeros(self.L)
+        self.l.ref_path_metrics(_dp(out))
+        return out
 
     def decode(self, y, sigma):
         y = np.ascontiguousarray(y, dtype=np.float64)

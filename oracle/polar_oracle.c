@@ -112,6 +112,14 @@ void po_polar_encode(int N, const int *u, int *x)
 
 /* ---- decoders: generic bodies ------------------------------------------------------------- */
 
+/* statistics of the last po_scl_decode_* call (test instrumentation, see polar_oracle_impl.h) */
+static __thread int po_last_key_fallbacks, po_last_triples;
+void po_scl_last_stats(int *out)
+{
+    out[0] = po_last_key_fallbacks;
+    out[1] = po_last_triples;
+}
+
 #define REAL double
 #define SFX f64
 #include "polar_oracle_impl.h"

@@ -65,6 +65,11 @@ int po_bpr_decode_f64(const po_code *c, const double *llr, int iters, const int 
 int po_scl_decode_f64(const po_code *c, const double *llr, int L, int crc, int *u_hat,
                       double *pm_out, int *ties_out);
 
+/* Statistics of this thread's last po_scl_decode_* call: out[0] = information leaves at which the 32-bit keys
+ * (float bits / high word of the double) do not single out exactly L candidates, i.e. where the kernels' ranking
+ * must fall back to full-width compares; out[1] = leaves with three or more equal candidates. */
+void po_scl_last_stats(int *out);
+
 /* float32 arithmetic variants (same operation order; used to check the f32 kernels) */
 int po_sc_decode_f32(const po_code *c, const float *llr, int *u_hat);
 int po_bp_decode_f32(const po_code *c, const float *llr, int iters, int *u_hat);
@@ -101,6 +106,21 @@ int po_run_sweep(const po_code *c, int algo, int L, int bp_iters, uint64_t seed,
 /* CRC helpers (CASCL_1024_L8.c:245-266 encode, :569-598 check) */
 void po_crc_encode(const po_code *c, const int *v /*K*/, int *w /*A*/);
 int po_crc_check(const po_code *c, const int *w /*A*/);
+
+/* ---- literal model of the reference's list decoder (polar_oracle_literal.c) ----
+ * The node records V[n+1][N] with per-path l, b, lDone, bDone as a PERSISTENT object, getLLR / updateBit /
+ * copyPath / simpleCopy on them exactly as SCL_1024.c:404-478 does it.  Identical to po_scl_decode_f64 on frames
+ * without a median tie; on a tie it does what the reference does (stale records, "Wrong propagation order!"),
+ * which depends on the frames decoded before.  diag[3] = counts of "Oops!" (:622), "Wrong propagation order!"
+ * (:418), "Error!" (:651). */
+typedef struct po_lit po_lit;
+po_lit *po_lit_create(const po_code *c, int L);
+void po_lit_destroy(po_lit *s);
+void po_lit_reset(po_lit *s);                       /* records as calloc() leaves them (SCL_1024.c:159-164) */
+void po_lit_poison(po_lit *s, uint64_t seed);      /* arbitrary leftovers in every record a frame does not initialise */
+int po_lit_decode(po_lit *s, const double *llr, int crc, int *u_hat, double *pm_out);
+void po_lit_diag(po_lit *s, long *out, int reset);
+void po_lit_path_metrics(const po_lit *s, double *out /* [L] */);
 
 /* Polar encode x = u * F^{(x)n}, natural order (SCL_1024.c:242-250 with Fn[i][j] = ((i&j)==j)) */
 void po_polar_encode(int N, const int *u, int *x);

@@ -247,6 +247,12 @@ static void FN(scl_clone)(FN(scl_ws) *w, int src, int dst, int j)
     memcpy(w->uh + (size_t)dst * w->N, w->uh + (size_t)src * w->N, (size_t)j);
 }
 
+static inline uint32_t FN(key32)(REAL v)
+{
+    if (sizeof(REAL) == 4) { float f = (float)v; uint32_t u; memcpy(&u, &f, 4); return u; }
+    double d = (double)v; uint64_t u; memcpy(&u, &d, 8); return (uint32_t)(u >> 32);
+}
+
 static int FN(cmp_real)(const void *a, const void *b)
 {
     REAL x = *(const REAL *)a, y = *(const REAL *)b;
@@ -272,6 +278,8 @@ int FN(po_scl_decode)(const po_code *c, const REAL *llr, int L, int crc, int *u_
     REAL lam[PO_MAX_L];
     int ties = 0;
     int act = 1;
+    po_last_key_fallbacks = 0;
+    po_last_triples = 0;
     PM[0] = 0; /* SCL_1024.c:556 */
     for (int j = 0; j < N; j++) {
         for (int k = 0; k < act; k++) lam[k] = FN(scl_leaf_llr)(&w, llr, k, j);
@@ -296,9 +304,26 @@ int FN(po_scl_decode)(const po_code *c, const REAL *llr, int L, int crc, int *u_
                 PM[k] = cand[k];
                 PM[k + L] = cand[k + L];
             }
+            { /* instrumentation for the tests of the kernels' two-step ranking (32-bit keys first: the float's bits /
+               * the double's high word, full width only if those do not single out exactly L candidates) */
+                int keep = 0;
+                for (int a = 0; a < 2 * L; a++) {
+                    int cnt = 0;
+                    for (int m = 0; m < 2 * L; m++) cnt += (FN(key32)(cand[m]) <= FN(key32)(cand[a]));
+                    keep += (cnt <= L);
+                }
+                if (keep != L) po_last_key_fallbacks++;
+            }
             qsort(cand, (size_t)2 * L, sizeof(REAL), FN(cmp_real)); /* QuickSort, :619 */
             REAL med = cand[L];
             if (cand[L - 1] == med) ties++; /* the reference prints "Oops!" (:621-622) */
+            { /* three or more keys equal to the pivot value somewhere: see polar_oracle_literal.c (Partition) */
+                int run = 1;
+                for (int a = 1; a < 2 * L; a++) {
+                    run = (cand[a] == cand[a - 1]) ? run + 1 : 1;
+                    if (run >= 3) { po_last_triples++; break; }
+                }
+            }
             for (int k = 0; k < L; k++) { /* :624-633 */
                 if (PM[k] < med && PM[k + L] < med) surviv[k] = 2;
                 else if (PM[k] >= med && PM[k + L] < med) surviv[k] = 1;

@@ -14,6 +14,7 @@
  * only the graph/frozen-set SET-UP, done with the reference's own connectBCB() and Q table.
  */
 #include <math.h>
+#include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,6 +32,27 @@ static int ref_scanf_int(int *dst)
     ref_scan_pos++;
     return 1;
 }
+/* The decoders report trouble on stdout ("Oops!" on a median tie SCL_1024.c:622, "Wrong propagation order!"
+ * :418, "Error!" :651): count those lines, and keep them off stdout while ref_decode() runs.  Everything else
+ * (the result lines of main()) is printed as written. */
+static long ref_diag_count[3];
+static int ref_diag_quiet = 0;
+static int ref_printf(const char *fmt, ...)
+{
+    static const char *const what[3] = {"Oops!", "Wrong propagation order!", "Error!"};
+    int a, rv;
+    va_list ap;
+    for (a = 0; a < 3; a++)
+        if (strncmp(fmt, what[a], strlen(what[a])) == 0) {
+            ref_diag_count[a]++;
+            if (ref_diag_quiet) return 0;
+        }
+    va_start(ap, fmt);
+    rv = vprintf(fmt, ap);
+    va_end(ap);
+    return rv;
+}
+#define printf ref_printf
 #define time(x) ((time_t)ref_time_value)
 #define scanf(fmt, p) ref_scanf_int(p)
 #define main ref_main
@@ -38,6 +60,7 @@ static int ref_scanf_int(int *dst)
 #undef main
 #undef scanf
 #undef time
+#undef printf
 
 /* From here on N, K, n (and L, r for the list decoders) are the reference's macros and `std` its
  * global noise deviation: no local identifier below may use those names. */
@@ -134,8 +157,45 @@ int ref_decode(const double *y, double sigma, int *u_hat)
 {
     if (!ref_ready) ref_init();
     std = sigma;
+    ref_diag_quiet = 1;
     REF_DECODE((double *)y, u_hat);
+    ref_diag_quiet = 0;
     return 0;
+}
+#endif
+
+/* counts of the three diagnostics since the last reset: out[0] "Oops!", out[1] "Wrong propagation order!", out[2] "Error!" */
+void ref_diag(long *out, int reset)
+{
+    int a;
+    for (a = 0; a < 3; a++) {
+        out[a] = ref_diag_count[a];
+        if (reset) ref_diag_count[a] = 0;
+    }
+}
+
+#if REF_KIND == 2 || REF_KIND == 3
+/* Put the node records back to what calloc() gave main() (SCL_1024.c:159-164): the list decoders never clear
+ * paths 1..L-1, so what they do after a median tie depends on what earlier frames left there. */
+void ref_reset_state(void)
+{
+    int a, b;
+    if (!ref_ready) ref_init();
+    for (a = 0; a <= REF_LOG; a++)
+        for (b = 0; b < REF_BLOCK; b++) {
+            memset(V[a][b]->l, 0, sizeof V[a][b]->l);
+            memset(V[a][b]->b, 0, sizeof V[a][b]->b);
+            memset(V[a][b]->lDone, 0, sizeof V[a][b]->lDone);
+            memset(V[a][b]->bDone, 0, sizeof V[a][b]->bDone);
+        }
+    memset(PM, 0, 2 * REF_LIST * sizeof(double));
+    memset(PMcand, 0, 2 * REF_LIST * sizeof(double));
+    memset(surviv, 0, sizeof surviv);
+}
+void ref_path_metrics(double *out)
+{
+    int a;
+    for (a = 0; a < REF_LIST; a++) out[a] = PM[a];
 }
 #endif
 

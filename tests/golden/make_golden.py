@@ -16,6 +16,16 @@ stores inputs + outputs:
 BPr_128_main_seed7.txt is the first 43 lines (three Eb/N0 points) of `oracle/_ref/BPr_128_main 7`, the compiled
 BPr_128.c main() with its time() seed pinned to 7 (4 minutes of CPU for all seven points).
 
+ties_<name>.npz (SCL_128, CASCL_128, SCL_1024, CASCL_1024_L8): frames on which the list decoders meet a MEDIAN TIE
+(SCL_1024.c:619-633), which AWGN inputs in double precision practically never produce: observations on a grid of
+1/64 with std = 0.5, so that the channel LLR 2*y/std/std = 8*y is exact and path metrics collide.  Per frame the
+compiled reference's u_hat, chosen-path metric and the number of "Oops!" / "Wrong propagation order!" / "Error!"
+lines it printed, decoded (a) from freshly calloc()ed node records and (b) one after the other without clearing
+anything, like main() does; frames from which the reference NEVER RETURNS (three equal candidates send its
+Partition(), SCL_1024.c:518-544, into an endless loop; found with a time limit in a child process) are kept with
+returns = 0; plus frames without a tie on which the high 32 bits of the candidates do not decide the ranking.
+make_ties() documents the fields.
+
 It also parses the reference's published fixed-seed logs (myResult_*.zip: data, not code) into
 published_runs.json: the known-answer run counts used by tests/test_oracle_kat.py.
 Only data is written here; no reference source text.
@@ -105,6 +115,93 @@ def make_bpr():
     print(f"{name}: {len(sig)} frames, iterMax {iters}, checkpoints {cp}, E total\n{np.array(Es).sum(axis=0)}")
 
 
+TIE_PROGRAMS = {"SCL_128": (16, 3, 8, 4), "CASCL_128": (16, 3, 8, 4), "SCL_1024": (6, 2, 4, 2),
+                "CASCL_1024_L8": (6, 2, 4, 2)}   # frames wanted: tie, never-returns, near-tie, clean
+TIE_GRID = 64.0
+TIE_SIGMA = 0.5
+
+
+def _probe_returns(name, y, limit=20.0):
+    """Does the compiled reference return from this frame (fresh records)?  Run in a child with a time limit."""
+    import subprocess
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".npy") as f:
+        np.save(f.name, y)
+        code = (f"import sys; sys.path.insert(0, {REPO!r}); import numpy as np; from oracle import oracle_py as O; "
+                f"r = O.Ref({name!r}); r.reset_state(); r.decode(np.load({f.name!r}), {TIE_SIGMA})")
+        try:
+            subprocess.run([sys.executable, "-c", code], timeout=limit, check=True)
+            return True
+        except subprocess.TimeoutExpired:
+            return False
+
+
+def make_ties(only=None):
+    """ties_<name>.npz:
+      sigma (scalar), y[F][N], kind[F] (0 tie, 1 reference never returns, 2 no tie but the candidates' high words do not
+      decide the ranking, 3 neither), returns[F],
+      u_hat[F][N], pm[F], diag[F][3]                : compiled reference, node records cleared before the frame
+      u_hat_seq[F][N], pm_seq[F], diag_seq[F][3]    : compiled reference, the frames with returns = 1 decoded in file
+                                                      order without clearing anything (records cleared once, before the first)
+    (rows of frames with returns = 0 are zero)."""
+    for name, want in TIE_PROGRAMS.items():
+        if only and name not in only and "ties" not in only:
+            continue
+        N, K, taps, algo, L = O.REF_PROGRAMS[name]
+        code = O.Code(N, K, taps)
+        ref = O.Ref(name)
+        lit = O.Literal(code, L, crc=(algo == "CASCL"))
+        sim = O.Sim(977 + N + len(name))
+        got = {0: [], 1: [], 2: [], 3: []}
+        tries = 0
+        while any(len(got[k]) < want[k] for k in range(4)) and tries < 20000:
+            tries += 1
+            _, y0 = sim.frame(code, O.sigma_from_db(1.0 if tries % 2 else 2.0))
+            y = np.round(y0 * TIE_GRID) / TIE_GRID
+            llr = O.llr_from_y(y, TIE_SIGMA)
+            assert np.array_equal(llr, 8 * y)
+            lit.reset()
+            _, _, d = lit.decode(llr)
+            st = np.zeros((1, 2), dtype=np.int32)
+            _, _, t = O.decode(code, llr, algo, L=L, stats=st)
+            if lit.last_rc == -5:
+                kind = 1
+            elif lit.last_rc != 0:
+                continue
+            elif d[0] > 0:
+                kind = 0
+            elif st[0, 0] > 0:
+                kind = 2
+            else:
+                kind = 3
+            if len(got[kind]) < want[kind]:
+                got[kind].append(y)
+        ys = np.array([y for k in range(4) for y in got[k]])
+        kinds = np.array([k for k in range(4) for _ in got[k]], dtype=np.int8)
+        F = len(ys)
+        ret = np.zeros(F, dtype=np.int8)
+        uh = np.zeros((F, N), dtype=np.uint8); pm = np.zeros(F); dg = np.zeros((F, 3), dtype=np.int64)
+        for f in range(F):
+            if kinds[f] == 1:
+                assert not _probe_returns(name, ys[f]), "the model says the reference loops here, the reference returned"
+                continue
+            ret[f] = 1
+            ref.reset_state(); ref.diag()
+            u, p = ref.decode(ys[f], TIE_SIGMA)
+            uh[f], pm[f], dg[f] = u, p, ref.diag()
+        uhs = np.zeros_like(uh); pms = np.zeros(F); dgs = np.zeros_like(dg)
+        ref.reset_state(); ref.diag()
+        for f in range(F):
+            if ret[f]:
+                u, p = ref.decode(ys[f], TIE_SIGMA)
+                uhs[f], pms[f], dgs[f] = u, p, ref.diag()
+        np.savez_compressed(os.path.join(HERE, f"ties_{name}.npz"), sigma=TIE_SIGMA, y=ys, kind=kinds, returns=ret,
+                            u_hat=uh, pm=pm, diag=dg, u_hat_seq=uhs, pm_seq=pms, diag_seq=dgs)
+        print(f"ties_{name}: {[len(got[k]) for k in range(4)]} frames (tie, never returns, near, clean) from {tries} draws; "
+              f"Oops per tie frame {dg[kinds == 0, 0].tolist()}, wrong-order {dg[kinds == 0, 1].tolist()}; "
+              f"fresh == in-sequence on {int(sum(np.array_equal(uh[f], uhs[f]) and pm[f] == pms[f] for f in range(F) if ret[f]))}/{int(ret.sum())}")
+
+
 def parse_log(text):
     """-> list of blocks {seed, L, rows:[(snr, errblock, run)]}"""
     blocks, cur = [], None
@@ -146,8 +243,10 @@ def make_published():
 
 
 if __name__ == "__main__":
-    only = sys.argv[1:] or None          # optional: names of the programs to regenerate
-    make_vectors(only)
+    only = sys.argv[1:] or None          # optional: names of the programs to regenerate ("ties": only the tie files)
+    if only != ["ties"]:
+        make_vectors(only)
+    make_ties(only)
     if not only or "BPr_128" in only:
         make_bpr()
     if not only:
