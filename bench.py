@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started without a launcher and with --gpus N > 1, the process that parsed the arguments touches no GPU: it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, passes rank 0's JSON line through and
+exits with the child's code.  Started by a launcher, --gpus must equal WORLD_SIZE.
+
 A "step" is one pass of the decode hot path (one kernel launch through the C ABI,
 polar_decode_device) over one batch of synthetic BPSK-AWGN frames per GPU, inputs (channel LLRs)
 already resident in HBM.  Steps alternate between two contexts / HIP streams per GPU, so the last,
@@ -18,31 +22,42 @@ sample).  The CPU oracle / reference is imported ONLY for that baseline leg.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import polardecoding_amd as pa  # noqa: E402
-from polardecoding_amd.synth import make_batch  # noqa: E402
-
+# torch and the HIP library are imported by the worker only (run()): the launching parent must never initialise a GPU
 N, K = 1024, 512
-CRC = pa.CRC24C_TAPS
+CRC = (0, 1, 2, 4, 8, 12, 13, 15, 17, 20, 21, 23, 24)   # CRC-24C, CASCL_1024_L8.c:2-4 (= polardecoding_amd.CRC24C_TAPS)
 R = max(CRC)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+TRAFFIC_PROFILE = "r01_traffic.json"   # latest committed rocprofv3 --pmc summary of the headline kernel
+
+
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
 
 def cpu_baseline(snr_db, seconds_target=15.0):
     """The reference's CASCL() itself (oracle/_ref/libCASCL_1024_L8.so, built from /root/reference by
     oracle/Makefile), one thread, decode call only, on frames of the same distribution."""
+    import numpy as np
     try:
         from oracle import oracle_py as O
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"oracle unavailable: {e}"}
+    cpu = f"{host_cpu_model()}, {os.cpu_count()} logical cores present, 1 used"
     code = O.Code(N, K, O.CRC24C_TAPS)
     sig = O.sigma_from_db(snr_db)
     sim = O.Sim(1024)
@@ -57,7 +72,8 @@ def cpu_baseline(snr_db, seconds_target=15.0):
         for _ in range(reps):
             tot += ref.time_decode(ys, sig)
         return {"value": reps * nfr / tot, "unit": "frames/s", "cores": 1, "kind": "reference",
-                "sample": f"{reps * nfr} frames @ {snr_db} dB, CASCL() of CASCL_1024_L8.c compiled gcc -O2, decode call only"}
+                "sample": f"{reps * nfr} frames @ {snr_db} dB, CASCL() of CASCL_1024_L8.c compiled gcc -O2 (oracle/_ref, "
+                          f"untracked build product of oracle/Makefile), decode call only; host: {cpu}"}
     nfr = 512
     us, ys = sim.frames(code, sig, nfr)
     llr = np.stack([O.llr_from_y(y, sig) for y in ys])
@@ -67,10 +83,10 @@ def cpu_baseline(snr_db, seconds_target=15.0):
         O.lib().po_decode_batch_f64(code._h, 3, 8, 0, llr.ctypes.data_as(O.C.POINTER(O.C.c_double)), nfr, None)
         cnt += nfr
     return {"value": cnt / (time.perf_counter() - t0), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{cnt} frames @ {snr_db} dB, build's C restatement (oracle/polar_oracle.c), single thread"}
+            "sample": f"{cnt} frames @ {snr_db} dB, build's C restatement (oracle/polar_oracle.c), single thread; host: {cpu}"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -81,7 +97,43 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--one-stream", action="store_true", help="all steps on one stream (no overlap of consecutive launches)")
     ap.add_argument("--streams", type=int, default=2, help="contexts / HIP streams the steps alternate over")
-    args = ap.parse_args()
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="no GPU: launcher, rendezvous (gloo), barriers, reductions and the JSON relay only; nothing is "
+                         "decoded and `value` is null (the world-size-2 CPU test of the N-rank path)")
+    return ap.parse_args(argv)
+
+
+def launch(args, argv):
+    """--gpus N > 1 without a launcher: be the launcher.  This process makes no GPU call (it has not even imported
+    torch); the ranks are children of torch.distributed.run, rank 0 prints the JSON line, which passes through."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this image
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch(args, argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    run(args)
+
+
+def run(args):
+    import numpy as np  # noqa: F401
+    import torch
+    import polardecoding_amd as pa
+    from polardecoding_amd.synth import make_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -91,7 +143,12 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if args.rehearse_cpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    if args.rehearse_cpu:
+        return rehearse(args, dist, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local)
@@ -139,7 +196,11 @@ def main():
     decs[last % len(decs)].count_errors_device(outs[last % len(decs)], batches[last & 1][1], counters)
     torch.cuda.synchronize()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    per_rank = [elapsed]
     if dist:
+        tall = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(tall, tmax)                   # every rank's own time: stragglers show in the 1 -> 8 curve
+        per_rank = [float(t.item()) for t in tall]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)
     elapsed = float(tmax.item())
@@ -152,15 +213,21 @@ def main():
     alg_bytes = B * (N * in_bytes + N // 8)  # LLRs in, packed bits out
     achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9
 
+    # HBM traffic and VALU counters cannot be read from inside this process: they come from separate rocprofv3 --pmc
+    # passes over this same command (tools/prof_pmc.sh), whose summary is committed as profiles/<round>_traffic.json
+    # together with the commit it was measured at.  Reported only for the profiled workload, and labelled as such.
     traffic = None
+    traffic_source = None
     valu = None
-    try:  # measured separately with rocprofv3 --pmc (profiles/README.md); only valid for the profiled workload
-        with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
-            tj = json.load(f).get(args.dtype)
+    try:
+        with open(os.path.join(REPO, "profiles", TRAFFIC_PROFILE)) as f:
+            tall_ = json.load(f)
+        tj = tall_.get(args.dtype)
         if tj and tj["frames_per_launch"] == B:
             traffic = (tj["fetch_kib"] + tj["write_kib"]) * 1024.0
+            traffic_source = f"from_profile: profiles/{TRAFFIC_PROFILE} (rocprofv3 --pmc, commit {tall_.get('commit', '?')}), not measured in this run"
             valu = {"busy_frac": tj.get("valu_busy_frac"), "insts_per_frame": tj.get("valu_insts_per_frame"),
-                    "source": "profiles/r01_k_scl_fast2_b131072.txt (rocprofv3 --pmc)"}
+                    "source": traffic_source}
     except Exception:
         traffic = None
 
@@ -190,6 +257,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "per_rank_frames_per_s": [B * args.steps / t for t in per_rank],
+            "single_launch_frames_per_s": B / ms_kernel * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -202,7 +271,7 @@ def main():
             "fer": {"block_errors": blk, "bit_errors": bits, "frames": world * B,
                     "fer": blk / float(world * B)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": dec.kernel_name, "kernel_ms": ms_kernel,
                          "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
                          "note": "path is VALU/LDS-bound, not HBM-bound (SURVEY.md 0.5); see DESIGN.md.  kernel_ms is one "
@@ -213,9 +282,42 @@ def main():
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.snr)
+            if out["cpu_baseline"].get("value"):
+                out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()   # rank 0 still measures the kernel-level figures after the timed region: leave together
+        dist.destroy_process_group()
+
+
+def rehearse(args, dist, rank, world):
+    """--rehearse-cpu: the N-rank control path without a GPU -- same barriers, same reductions (gloo instead of RCCL),
+    same JSON relay; the step is empty and `value` is null.  Nothing here is a measurement."""
+    import torch
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64)
+    counters = torch.tensor([rank + 1, 10 * (rank + 1)], dtype=torch.int64)   # stand-ins for (block, bit) errors
+    per_rank = [elapsed]
+    if dist:
+        tall = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(tall, tmax)
+        per_rank = [float(t.item()) for t in tall]
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "decoded frames/sec, N=1024 K=512 CA-SCL L=8", "value": None, "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "rehearsal": True,
+                          "ranks_seen": len(per_rank), "counter_sum": [int(v) for v in counters.tolist()],
+                          "note": "--rehearse-cpu: launcher / rendezvous / reductions only, nothing decoded"}), flush=True)
+    if dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -47,6 +47,10 @@ extern "C" {
 /* per-frame flags word */
 #define POLAR_FLAG_TIE 0x1u      /* a median tie occurred (reference prints "Oops!", SCL_1024.c:621-622) */
 #define POLAR_FLAG_CRC_PASS 0x2u /* CASCL: the chosen path passed the CRC (CASCL_1024_L8.c:738-746)       */
+#define POLAR_FLAG_RERANK 0x4u   /* diagnostic, no reference counterpart: at some information leaf the high 32 bits of
+                                    the 2L candidate metrics did not single out L survivors and the kernel ranked on
+                                    the full doubles (f64 list kernels that pre-rank on 32-bit keys; same result either
+                                    way -- the bit lets the tests see that rare path run)                              */
 
 typedef struct polar_ctx polar_ctx;
 
@@ -116,6 +120,21 @@ int polar_decode_device(polar_ctx *ctx, const void *d_in, int in_is_f32, double 
  * the reference's sequential stop rule). */
 int polar_count_errors_device(polar_ctx *ctx, const uint32_t *d_uhat_bits, const uint32_t *d_u_bits, size_t B,
                               unsigned long long *d_counters, uint32_t *d_frame_err);
+
+/* --- the sequential stop rule on a batch (`for (run = 0; errBlock < BLE; run++)`, SCL_1024.c:228, :264-275) -------
+ * The reference ends an Eb/N0 point WITH the frame that brings the block errors to BLE; generator state and PN phase
+ * carry on from there.  For a batch decoded as a whole that is a prefix count over polar_count_errors_device's
+ * d_frame_err, done on the device: d_out[0] = frames consumed (position of the `need`-th erroneous frame + 1, or B if
+ * the batch holds fewer), d_out[1] / d_out[2] = block / bit errors among the consumed frames.  need >= 1. */
+int polar_stop_rule_cut_device(polar_ctx *ctx, const uint32_t *d_frame_err, size_t B, unsigned need,
+                               unsigned long long *d_out /* [3] */);
+
+/* Host-buffer form, one iteration of main()'s loop over a batch: y [B][N] observations, sigma = std, u_bits [B][N/32]
+ * the sent u packed like the decisions.  Decode, compare on the unfrozen positions (:266-272; payload only with
+ * crc_systematic) and cut, all on the device; only three numbers come back. */
+int polar_stop_rule_batch_y(polar_ctx *ctx, const double *y, double sigma, const uint32_t *u_bits, size_t B,
+                            unsigned need, size_t *consumed, unsigned long long *block_errors,
+                            unsigned long long *bit_errors);
 
 /* --- BP with per-stage read-outs (BPr_128.c:373-575: `BPr(y, u_hat, u)` and its table E[7][n+1]) -----------------
  * ctx must be a POLAR_ALGO_BP context (its bp_iters = the program's iterMax, 90 in BPr_128.c:16).  After each of the

@@ -171,6 +171,17 @@ def decode(code, llr, algo, L=8, bp_iters=100, dtype="f64", stats=None):
     return uh, pm, ties
 
 
+def math(op, a, b, dtype=np.float64):
+    """CHK / T / PHI of the oracle element-wise: op 0 CHK(a, b), 1 T(|a|), 2 PHI(a, u = (b != 0))."""
+    a = np.ascontiguousarray(a, dtype=dtype).ravel()
+    b = np.ascontiguousarray(np.broadcast_to(np.asarray(b, dtype=dtype), a.shape), dtype=dtype).ravel()
+    out = np.empty_like(a)
+    fn = lib().po_math_f32 if dtype == np.float32 else lib().po_math_f64
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    fn(int(op), a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size)
+    return out
+
+
 class Literal:
     """The reference's list decoder WITH its persistent node records (oracle/polar_oracle_literal.c): what
     SCLdecode / CASCL do frame after frame, including after a median tie.  decode() -> (u_hat, pm, diag[3]) with

@@ -70,6 +70,11 @@ int po_scl_decode_f64(const po_code *c, const double *llr, int L, int crc, int *
  * must fall back to full-width compares; out[1] = leaves with three or more equal candidates. */
 void po_scl_last_stats(int *out);
 
+/* The scalar arithmetic on chosen operands: op 0 CHK(a, b) (SCL_1024.c:343-374), 1 T(|a|) (:352-359),
+ * 2 PHI(a, u = (b != 0)) (:481-502). */
+void po_math_f64(int op, const double *a, const double *b, double *out, size_t cnt);
+void po_math_f32(int op, const float *a, const float *b, float *out, size_t cnt);
+
 /* float32 arithmetic variants (same operation order; used to check the f32 kernels) */
 int po_sc_decode_f32(const po_code *c, const float *llr, int *u_hat);
 int po_bp_decode_f32(const po_code *c, const float *llr, int iters, int *u_hat);

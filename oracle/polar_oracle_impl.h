@@ -43,6 +43,17 @@ static inline REAL FN(phi)(REAL lam, int u)
     return result;
 }
 
+/* element-wise CHK / T / PHI on caller-chosen operands (tests of the kernels' table arithmetic at its boundaries):
+ * op 0 CHK(a, b), 1 T(|a|), 2 PHI(a, u = (b != 0)) */
+void FN(po_math)(int op, const REAL *a, const REAL *b, REAL *out, size_t cnt)
+{
+    for (size_t i = 0; i < cnt; i++) {
+        if (op == 0) out[i] = FN(chk)(a[i], b[i]);
+        else if (op == 1) out[i] = FN(tab)(PO_ABS(a[i]));
+        else out[i] = FN(phi)(a[i], b[i] != 0);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * SC (SC_128.c:395-460): natural-order recursion.  alpha level t lives at
  * offset 2^t of a length-N scratch; bl = saved left-child partial sums, same layout.

@@ -16,7 +16,7 @@ import numpy as np
 
 ALGO_SC, ALGO_BP, ALGO_SCL, ALGO_CASCL = 0, 1, 2, 3
 F64, F32 = 0, 1
-FLAG_TIE, FLAG_CRC_PASS = 1, 2
+FLAG_TIE, FLAG_CRC_PASS, FLAG_RERANK = 1, 2, 4
 CRC6_TAPS = (0, 5, 6)  # g(D) = D^6 + D^5 + 1 (CASCL_128.c:3)
 CRC24C_TAPS = (0, 1, 2, 4, 8, 12, 13, 15, 17, 20, 21, 23, 24)  # CASCL_1024_L8.c:2-4
 
@@ -35,8 +35,7 @@ class _Cfg(C.Structure):
 
 
 def lib_path():
-    # POLAR_HIP_LIB: developer override (timing experiments with instrumented builds of the same library)
-    return os.environ.get("POLAR_HIP_LIB") or os.path.join(_HERE, "lib", "libpolar_hip.so")
+    return os.path.join(_HERE, "lib", "libpolar_hip.so")
 
 
 _lib = None

@@ -379,4 +379,62 @@ __global__ __launch_bounds__(256) void k_count_errors(CountParams P)
     }
 }
 
+// ---- the reference's sequential stop rule on a batch -------------------------------------------------
+// main() decodes frame after frame `for (run = 0; errBlock < BLE; run++)` (SCL_1024.c:228, counters :264-275):
+// the point ends WITH the frame that brings the block errors to BLE.  On a batch that was decoded as a whole this
+// is a prefix count over the per-frame error counts k_count_errors wrote: out[0] = frames consumed (index of the
+// `need`-th erroneous frame + 1, or B if the batch does not contain that many), out[1] / out[2] = block / bit
+// errors among the consumed frames.  One workgroup: B words are read twice, which is nothing next to the decode.
+__global__ __launch_bounds__(1024) void k_stop_cut(const uint32_t *frame_err, int B, unsigned need, unsigned long long *out)
+{
+    __shared__ unsigned wcnt[16];
+    __shared__ unsigned long long wbits[16];
+    __shared__ unsigned base_s;
+    __shared__ int cut_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) { base_s = 0; cut_s = B; }
+    __syncthreads();
+    for (int s0 = 0; s0 < B; s0 += 1024) {   // pass 1: where is the need-th erroneous frame?
+        const int f = s0 + tid;
+        const bool bad = f < B && frame_err[f] != 0;
+        const unsigned long long m = __ballot(bad);
+        if (lane == 0) wcnt[w] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned before = base_s;
+        for (int q = 0; q < w; ++q) before += wcnt[q];
+        const unsigned rank = before + (unsigned)__popcll(m & ((1ull << lane) - 1ull)) + 1u;   // 1-based, if bad
+        if (bad && rank == need) cut_s = f + 1;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned t = base_s;
+            for (int q = 0; q < 16; ++q) t += wcnt[q];
+            base_s = t;
+        }
+        __syncthreads();
+        if (cut_s != B || base_s >= need) break;   // uniform: both are shared and were written before the barrier
+    }
+    const int cut = cut_s;
+    unsigned blk = 0;
+    unsigned long long bits = 0;
+    for (int f = tid; f < cut; f += 1024) {   // pass 2: the counters over the consumed frames
+        const uint32_t e = frame_err[f];
+        blk += (e != 0);
+        bits += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        blk += __shfl_down(blk, o);
+        bits += __shfl_down(bits, o);
+    }
+    __syncthreads();
+    if (lane == 0) { wcnt[w] = blk; wbits[w] = bits; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long tb = 0, tbits = 0;
+        for (int q = 0; q < 16; ++q) { tb += wcnt[q]; tbits += wbits[q]; }
+        out[0] = (unsigned long long)cut;
+        out[1] = tb;
+        out[2] = tbits;
+    }
+}
+
 }  // namespace polar

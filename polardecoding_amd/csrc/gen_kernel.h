@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void k_generate(GenParams P)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = k2 + h;
+                if (k >= KR) break;   // N = 64: one element per lane, the second normal of the pair is not used
                 const int j = lane + 64 * k;
                 const double y = (((x >> k) & 1ull) ? -1.0 : 1.0) + P.sigma * nz[h];
                 const double v = P.out_is_y ? y : 2 * y / P.sigma / P.sigma;

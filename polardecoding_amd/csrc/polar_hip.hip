@@ -1,6 +1,7 @@
 // polar_hip.hip -- C ABI (include/polar_hip.h) over the hand-written gfx950 kernels.
 // Host side: code construction (frozen set, CRC table), kernel dispatch, buffers, stream.
 #include "../../include/polar_hip.h"
+#include "../../include/polar_hip_testing.h"
 
 #include <hip/hip_runtime.h>
 
@@ -16,6 +17,7 @@
 
 #include "bp_kernel.h"
 #include "gen_kernel.h"
+#include "probe_kernel.h"
 #include "scl_fast.h"
 #include "scl_fast2.h"
 #include "scl_generic.h"
@@ -64,13 +66,32 @@ struct polar_ctx {
     hipEvent_t ev_b = nullptr;
     std::string last_error;
     std::string kernel_name;
+    // kernel selection overrides, set only through include/polar_hip_testing.h (cross-checks of the tuned kernels)
     bool force_generic = false;
-    bool use_fast2 = true;      // POLAR_FAST2=0: one codeword per wavefront (k_scl_fast) instead of two
-    bool force_spill = false;   // POLAR_FORCE_SPILL=1: exercise the global-scratch variant on shapes that would fit LDS
+    bool use_fast2 = true;      // false: one codeword per wavefront (k_scl_fast) instead of two at N = 1024
+    bool force_spill = false;   // no tuned L = 8 kernel; with force_generic: the global-scratch variant of k_scl_generic
+    int big_split = 0;          // 35 | 46 | 57: LDS / scratch split of k_scl_big; 0 = the measured best
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 namespace {
+
+// Every entry point that allocates or launches runs on the ctx's device whatever the calling thread had current,
+// and leaves the thread's current device as it found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 
 int fail(polar_ctx *c, hipError_t e, const char *what)
 {
@@ -223,12 +244,11 @@ static bool sc_lanes_ok(const polar_ctx *c, size_t B)
     return c->cfg.algo == POLAR_ALGO_SC && !c->force_generic && c->cfg.N <= 2048 && B >= 64;
 }
 
-// the LDS / scratch split that measured best per arithmetic type (profiles/README.md); POLAR_BIG_SPLIT=35|46|57 overrides
+// the LDS / scratch split that measured best per arithmetic type (profiles/README.md)
 template <typename R, typename IN, int LOGL>
 int launch_big(polar_ctx *c, const polar::SclParams &P)
 {
-    static const int split = getenv("POLAR_BIG_SPLIT") ? atoi(getenv("POLAR_BIG_SPLIT")) : 0;
-    const int use = split ? split : (sizeof(R) == 8 ? 35 : 46);
+    const int use = c->big_split ? c->big_split : (sizeof(R) == 8 ? 35 : 46);
     if (use == 57) return launch_big_v<R, IN, LOGL, 5, 7>(c, P);
     if (use == 46) return launch_big_v<R, IN, LOGL, 4, 6>(c, P);
     return launch_big_v<R, IN, LOGL, 3, 5>(c, P);
@@ -408,26 +428,8 @@ int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sig
     P.sc_mode = (g.algo == POLAR_ALGO_SC) ? 1 : 0;
     P.dbg = nullptr;
     P.scratch = nullptr;
-#ifdef POLAR_STAMPS
-    static unsigned long long *s_dbg = nullptr;
-    if (!s_dbg) {
-        (void)hipMalloc(&s_dbg, 8 * sizeof(unsigned long long));
-        (void)hipMemset(s_dbg, 0, 8 * sizeof(unsigned long long));
-        atexit([] {
-            unsigned long long h[8];
-            (void)hipMemcpy(h, s_dbg, sizeof h, hipMemcpyDeviceToHost);
-            const char *nm_fast[8] = {"prologue", "load ch", "tl+init", "octet_head (d<6)", "octet frozen-prefix", "octet generic",
-                                      "select+store", "octet_head (d>=6, scratch levels)"};
-            const char *nm_big[8] = {"prologue+channel", "upper levels t>=6", "upper levels t<6", "LDS levels", "frozen / phase-1 leaf",
-                                     "phase-2 decision", "partial sums", "select+store"};
-            const char **nm = getenv("POLAR_STAMPS_BIG") ? nm_big : nm_fast;
-            unsigned long long tot = 0;
-            for (int i = 0; i < 8; ++i) tot += h[i];
-            for (int i = 0; i < 8; ++i)
-                fprintf(stderr, "[stamps] %-22s %14llu ticks  %5.1f %%\n", nm[i], h[i], 100.0 * h[i] / (tot ? tot : 1));
-        });
-    }
-    P.dbg = s_dbg;
+#ifdef POLAR_STAMPS   // diagnostic builds only (tools/): per-section cycle sums, see debug_stamps.inc
+#include "debug_stamps.inc"
 #endif
     if (sc_lanes_ok(c, B)) {
         if (!f32) return in_is_f32 ? launch_sc_lanes<double, float>(c, P) : launch_sc_lanes<double, double>(c, P);
@@ -440,6 +442,25 @@ int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sig
     }
     if (f32) return in_is_f32 ? launch_scl_l<float, float>(c, P) : launch_scl_l<float, double>(c, P);
     return in_is_f32 ? launch_scl_l<double, float>(c, P) : launch_scl_l<double, double>(c, P);
+}
+
+// the kernel instantiation decode_device_impl will launch for this ctx (mirrors its choices)
+void refresh_kernel_name(polar_ctx *c)
+{
+    const polar_cfg &g = c->cfg;
+    const char *ty = g.dtype == POLAR_F32 ? "float" : "double";
+    char nm[128];
+    if (g.algo == POLAR_ALGO_BP)
+        snprintf(nm, sizeof nm, "k_bp<%s>", ty);
+    else
+        snprintf(nm, sizeof nm, "k_scl_generic<%s,L=%d>", ty, g.L);
+    if (g.algo != POLAR_ALGO_BP && g.algo != POLAR_ALGO_SC && !c->force_generic && c->n >= 9 && g.L >= 2)
+        snprintf(nm, sizeof nm, "k_scl_big<%s,L=%d>", ty, g.L);
+    if (g.algo == POLAR_ALGO_SC && !c->force_generic && g.N <= 2048)
+        snprintf(nm, sizeof nm, "k_sc_lanes<%s> (batches of 64+; k_scl_generic below)", ty);
+    if (fast_ok(c, g.dtype == POLAR_F32))
+        snprintf(nm, sizeof nm, "k_scl_fast%s<%s,N=%d,L=8>", (g.N == 1024 && c->use_fast2) ? "2" : "", ty, g.N);
+    c->kernel_name = nm;
 }
 
 std::vector<uint32_t> pack_mask(const unsigned char *m, int N, bool invert)
@@ -473,6 +494,7 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
                int *u_hat, double *pm_out, unsigned *flags)
 {
     if (!c || !in || !u_hat) return POLAR_EINVAL;
+    DeviceGuard guard(c->cfg.device);
     if (B == 0) return POLAR_OK;
     const int N = c->cfg.N, NW = c->NW;
     const uint32_t *d_frozen = c->d_frozen;
@@ -640,13 +662,14 @@ int polar_create(const polar_cfg *cfg, polar_ctx **out)
     }
     c->h_crc_tab = make_crc_table(N, r, c->taps, c->info_order);
 
-    hipError_t e = hipSetDevice(cfg->device);
-    if (e != hipSuccess) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) {
         delete c;
         return POLAR_EDEVICE;
     }
+    DeviceGuard guard(cfg->device);   // the calling thread's current device is restored on return
     hipDeviceProp_t prop;
-    e = hipGetDeviceProperties(&prop, cfg->device);
+    hipError_t e = hipGetDeviceProperties(&prop, cfg->device);
     if (e != hipSuccess) {
         delete c;
         return POLAR_EDEVICE;
@@ -692,35 +715,7 @@ int polar_create(const polar_cfg *cfg, polar_ctx **out)
         if (hipMemcpy(c->d_crc_tab, c->h_crc_tab.data(), N * 4, hipMemcpyHostToDevice) != hipSuccess)
             return cleanup(POLAR_EDEVICE);
     }
-    char nm[128];
-    if (cfg->algo == POLAR_ALGO_BP)
-        snprintf(nm, sizeof nm, "k_bp<%s>", cfg->dtype == POLAR_F32 ? "float" : "double");
-    else
-        snprintf(nm, sizeof nm, "k_scl_generic<%s,L=%d>", cfg->dtype == POLAR_F32 ? "float" : "double", L);
-    c->kernel_name = nm;
-    if (const char *e = getenv("POLAR_FORCE_GENERIC")) c->force_generic = (e[0] == '1');
-    if (const char *e = getenv("POLAR_FORCE_SPILL")) c->force_spill = (e[0] == '1');
-    if (const char *e = getenv("POLAR_FAST2")) c->use_fast2 = (e[0] != '0');
-    {   // mirrors launch_scl's choice
-        const size_t rs = cfg->dtype == POLAR_F32 ? 4 : 8;
-        const size_t lut = cfg->dtype == POLAR_F32 ? polar::Lut<float>::bytes : polar::Lut<double>::bytes;
-        const size_t gen_lds = rs * (size_t)N * (1 + L) + 8 * (size_t)(N / 32) * L + rs * 2 * L + 16 + lut;
-        (void)gen_lds;
-        if (cfg->algo != POLAR_ALGO_BP && cfg->algo != POLAR_ALGO_SC && !c->force_generic && c->n >= 9 &&
-            L >= 2) {
-            snprintf(nm, sizeof nm, "k_scl_big<%s,L=%d>", cfg->dtype == POLAR_F32 ? "float" : "double", L);
-            c->kernel_name = nm;
-        }
-    }
-    if (cfg->algo == POLAR_ALGO_SC && !c->force_generic && N <= 2048) {
-        snprintf(nm, sizeof nm, "k_sc_lanes<%s> (batches of 64+; k_scl_generic below)", cfg->dtype == POLAR_F32 ? "float" : "double");
-        c->kernel_name = nm;
-    }
-    if (fast_ok(c, cfg->dtype == POLAR_F32)) {
-        snprintf(nm, sizeof nm, "k_scl_fast%s<%s,N=%d,L=8>", (N == 1024 && c->use_fast2) ? "2" : "",
-                 cfg->dtype == POLAR_F32 ? "float" : "double", N);
-        c->kernel_name = nm;
-    }
+    refresh_kernel_name(c);
     *out = c;
     return POLAR_OK;
 }
@@ -728,7 +723,7 @@ int polar_create(const polar_cfg *cfg, polar_ctx **out)
 void polar_destroy(polar_ctx *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->cfg.device);
+    DeviceGuard guard(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
@@ -759,6 +754,7 @@ void polar_destroy(polar_ctx *c)
 int polar_set_stream(polar_ctx *c, void *s)
 {
     if (!c) return POLAR_EINVAL;
+    DeviceGuard guard(c->cfg.device);
     if (c->own_stream && c->stream) {
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamDestroy(c->stream);
@@ -773,6 +769,7 @@ void *polar_get_stream(polar_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int polar_synchronize(polar_ctx *c)
 {
     if (!c) return POLAR_EINVAL;
+    DeviceGuard guard(c->cfg.device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return POLAR_OK;
 }
@@ -802,6 +799,7 @@ int polar_decode_device(polar_ctx *c, const void *d_in, int in_is_f32, double si
                         double *d_pm, uint32_t *d_flags)
 {
     if (!c) return POLAR_EINVAL;
+    DeviceGuard guard(c->cfg.device);
     return decode_device_impl(c, d_in, in_is_f32, sigma, B, d_bits, d_pm, d_flags, c->d_frozen);
 }
 
@@ -827,11 +825,15 @@ int polar_decode(polar_ctx *c, const double *y, double sigma, int *u_hat)
 int polar_decode_llr(const double *llr_in, const unsigned char *frozen_mask, int N, int L, int *u_hat)
 {
     if (!llr_in || !frozen_mask || !u_hat) return POLAR_EINVAL;
+    if (N < 32 || N > 4096 || (N & (N - 1)) || L < 1 || L > 32 || (L & (L - 1))) return POLAR_EINVAL;   // before frozen_mask[0..N) is read
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return POLAR_EDEVICE;
     static std::mutex mu;
     static std::vector<std::pair<std::vector<unsigned char>, polar_ctx *>> cache;
     std::lock_guard<std::mutex> lock(mu);
-    std::vector<unsigned char> key(frozen_mask, frozen_mask + N);
+    std::vector<unsigned char> key(frozen_mask, frozen_mask + N);   // key = (mask, L, device): a ctx is bound to one GPU
     key.push_back((unsigned char)L);
+    key.push_back((unsigned char)dev);
     polar_ctx *c = nullptr;
     for (auto &kv : cache)
         if (kv.first == key) c = kv.second;
@@ -845,8 +847,6 @@ int polar_decode_llr(const double *llr_in, const unsigned char *frozen_mask, int
         g.algo = (L == 1) ? POLAR_ALGO_SC : POLAR_ALGO_SCL;
         g.info_order = info.data();
         g.dtype = POLAR_F64;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
         g.device = dev;
         int rc = polar_create(&g, &c);
         if (rc) return rc;
@@ -865,6 +865,7 @@ int polar_bp_readout_device(polar_ctx *c, const void *d_in, int in_is_f32, doubl
 {
     if (!c || !d_in || !d_u_bits || !checkpoints || !d_E) return POLAR_EINVAL;
     if (c->cfg.algo != POLAR_ALGO_BP || ncp < 1 || ncp > 8 || B > 0x7fffffffull) return POLAR_EINVAL;
+    DeviceGuard guard(c->cfg.device);
     if (B == 0) return POLAR_OK;
     polar::BpReadoutParams P{};
     for (int i = 0; i < ncp; ++i) {
@@ -886,6 +887,7 @@ int polar_bp_readout_batch(polar_ctx *c, const double *in, double sigma, size_t 
 {
     if (!c || !in || !u || !checkpoints || !E) return POLAR_EINVAL;
     if (ncp < 1 || ncp > 8) return POLAR_EINVAL;
+    DeviceGuard guard(c->cfg.device);
     if (B == 0) return POLAR_OK;
     const int N = c->cfg.N, NW = c->NW, n = c->n;
     int rc;
@@ -918,6 +920,7 @@ int polar_count_errors_device(polar_ctx *c, const uint32_t *d_uhat, const uint32
                               unsigned long long *d_counters, uint32_t *d_frame_err)
 {
     if (!c || !d_uhat || !d_u || !d_counters) return POLAR_EINVAL;
+    DeviceGuard guard(c->cfg.device);
     if (B == 0) return POLAR_OK;
     polar::CountParams P{d_uhat, d_u, c->d_info, d_counters, d_frame_err, c->NW, (int)B};
     const int waves_per_block = 4;
@@ -927,10 +930,56 @@ int polar_count_errors_device(polar_ctx *c, const uint32_t *d_uhat, const uint32
     return POLAR_OK;
 }
 
+int polar_stop_rule_cut_device(polar_ctx *c, const uint32_t *d_frame_err, size_t B, unsigned need, unsigned long long *d_out)
+{
+    if (!c || !d_frame_err || !d_out || need < 1 || B > 0x7fffffffull) return POLAR_EINVAL;
+    DeviceGuard guard(c->cfg.device);
+    if (B == 0) {
+        HIP_TRY(c, hipMemsetAsync(d_out, 0, 3 * sizeof(unsigned long long), c->stream));
+        return POLAR_OK;
+    }
+    hipLaunchKernelGGL(polar::k_stop_cut, dim3(1), dim3(1024), 0, c->stream, d_frame_err, (int)B, need, d_out);
+    HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
+int polar_stop_rule_batch_y(polar_ctx *c, const double *y, double sigma, const uint32_t *u_bits, size_t B, unsigned need,
+                            size_t *consumed, unsigned long long *block_errors, unsigned long long *bit_errors)
+{
+    if (!c || !y || !u_bits || !consumed || !block_errors || !bit_errors || need < 1 || !(sigma > 0)) return POLAR_EINVAL;
+    *consumed = 0; *block_errors = 0; *bit_errors = 0;
+    if (B == 0) return POLAR_OK;
+    if (B > 0x7fffffffull) return POLAR_EINVAL;
+    DeviceGuard guard(c->cfg.device);
+    const int N = c->cfg.N, NW = c->NW;
+    int rc;
+    if ((rc = ensure(c, c->in, B * N * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->bits, B * NW * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->gen_u, B * NW * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->flags, B * sizeof(uint32_t)))) return rc;           // per-frame error counts
+    if ((rc = ensure(c, c->gen_cnt, 5 * sizeof(unsigned long long)))) return rc;   // [0..2) totals, [2..5) the cut
+    unsigned long long *cnt = (unsigned long long *)c->gen_cnt.p;
+    HIP_TRY(c, hipMemcpyAsync(c->in.p, y, B * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->gen_u.p, u_bits, B * NW * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(cnt, 0, 5 * sizeof(unsigned long long), c->stream));
+    if ((rc = decode_device_impl(c, c->in.p, 0, sigma, B, (uint32_t *)c->bits.p, nullptr, nullptr, c->d_frozen))) return rc;
+    if ((rc = polar_count_errors_device(c, (uint32_t *)c->bits.p, (uint32_t *)c->gen_u.p, B, cnt, (uint32_t *)c->flags.p)))
+        return rc;
+    if ((rc = polar_stop_rule_cut_device(c, (uint32_t *)c->flags.p, B, need, cnt + 2))) return rc;
+    unsigned long long h[3];
+    HIP_TRY(c, hipMemcpyAsync(h, cnt + 2, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *consumed = (size_t)h[0];
+    *block_errors = h[1];
+    *bit_errors = h[2];
+    return POLAR_OK;
+}
+
 int polar_generate_device(polar_ctx *c, unsigned long long seed, unsigned long long first_frame, double snr_db,
                           size_t B, void *d_out, int out_is_f32, int out_is_y, uint32_t *d_u_bits)
 {
     if (!c || !d_out || B > 0x7fffffffull) return POLAR_EINVAL;
+    DeviceGuard guard(c->cfg.device);
     if (B == 0) return POLAR_OK;
     const polar_cfg &g = c->cfg;
     if (g.N < 64) return POLAR_EINVAL;
@@ -963,6 +1012,7 @@ int polar_fer_batch(polar_ctx *c, unsigned long long seed, unsigned long long fi
                     unsigned long long *block_errors, unsigned long long *bit_errors)
 {
     if (!c || !block_errors || !bit_errors) return POLAR_EINVAL;
+    DeviceGuard guard(c->cfg.device);
     if (B == 0) return POLAR_OK;
     const int N = c->cfg.N, NW = c->NW;
     const bool f32 = c->cfg.dtype == POLAR_F32;
@@ -1013,10 +1063,60 @@ int polar_fer_batch(polar_ctx *c, unsigned long long seed, unsigned long long fi
     return POLAR_OK;
 }
 
+// ---- include/polar_hip_testing.h ----------------------------------------------------------------------------
+int polar_testing_select_kernel(polar_ctx *c, int variant)
+{
+    if (!c || variant < POLAR_TEST_KERNEL_AUTO || variant > POLAR_TEST_KERNEL_ONE_PER_WAVE) return POLAR_EINVAL;
+    c->force_generic = (variant == POLAR_TEST_KERNEL_GENERIC || variant == POLAR_TEST_KERNEL_GENERIC_SPILL);
+    c->force_spill = (variant == POLAR_TEST_KERNEL_GENERIC_SPILL || variant == POLAR_TEST_KERNEL_BIG);
+    c->use_fast2 = (variant != POLAR_TEST_KERNEL_ONE_PER_WAVE);
+    refresh_kernel_name(c);
+    return POLAR_OK;
+}
+
+int polar_testing_big_split(polar_ctx *c, int split)
+{
+    if (!c || (split != 0 && split != 35 && split != 46 && split != 57)) return POLAR_EINVAL;
+    c->big_split = split;
+    return POLAR_OK;
+}
+
+int polar_testing_math(int op, int is_f32, const void *a, const void *b, void *out, size_t n, int device)
+{
+    if (op < 0 || op > polar::PROBE_PHI_LUT || !a || !b || !out) return POLAR_EINVAL;
+    if (n == 0) return POLAR_OK;
+    DeviceGuard guard(device);
+    const size_t es = is_f32 ? 4 : 8;
+    void *da = nullptr, *db = nullptr, *d_out = nullptr;
+    int rc = POLAR_OK;
+    if (hipMalloc(&da, n * es) != hipSuccess || hipMalloc(&db, n * es) != hipSuccess || hipMalloc(&d_out, n * es) != hipSuccess)
+        rc = POLAR_ENOMEM;
+    if (!rc && (hipMemcpy(da, a, n * es, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(db, b, n * es, hipMemcpyHostToDevice) != hipSuccess))
+        rc = POLAR_EDEVICE;
+    if (!rc) {
+        const int grid = (int)std::min<size_t>((n + 255) / 256, 1024);
+        if (is_f32)
+            hipLaunchKernelGGL(polar::k_probe_math<float>, dim3(grid), dim3(256), polar::Lut<float>::bytes, 0, op,
+                               (const float *)da, (const float *)db, (float *)d_out, n);
+        else
+            hipLaunchKernelGGL(polar::k_probe_math<double>, dim3(grid), dim3(256), polar::Lut<double>::bytes, 0, op,
+                               (const double *)da, (const double *)db, (double *)d_out, n);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(out, d_out, n * es, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = POLAR_EDEVICE;
+    }
+    if (da) (void)hipFree(da);
+    if (db) (void)hipFree(db);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
 int polar_time_decode_device(polar_ctx *c, const void *d_in, int in_is_f32, double sigma, size_t B,
                              uint32_t *d_bits, int reps, float *ms)
 {
     if (!c || !ms || reps < 1) return POLAR_EINVAL;
+    DeviceGuard guard(c->cfg.device);
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < reps; ++i) {
         int rc = decode_device_impl(c, d_in, in_is_f32, sigma, B, d_bits, nullptr, nullptr, c->d_frozen);

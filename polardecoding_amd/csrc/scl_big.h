@@ -326,6 +326,7 @@ __global__ __launch_bounds__(256) void k_scl_big(SclParams P)
                 uint64_t m_s1 = __ballot(pos == 1 && cnt <= L) >> 1;   // aligned to the lead lanes
                 if (__popcll(m_s0) + __popcll(m_s1) < L) {
                     // strict "< med" with med = (L+1)-th smallest  <=>  #{m : c_m <= c} <= L
+                    if (sizeof(R) == 8) fl |= 0x4u;   // POLAR_FLAG_RERANK (a float's key is the float: only a tie gets here)
                     if (pos < 2) cand[2 * p + pos] = mine;
                     __asm__ volatile("" ::: "memory");
                     cnt = 0;

@@ -524,6 +524,7 @@ struct FastDec {
         uint32_t mask = (uint32_t)__ballot(cnt <= (uint32_t)L) & 0xFFFFu;
         if (sizeof(R) == 8 && __popc(mask) != L) {
             // keys tie across the boundary (or a true median tie): decide on the full metrics
+            fl |= 0x4u;   // POLAR_FLAG_RERANK
             lds_fence();
             if (pos == 0) {
                 cand[p] = c0;

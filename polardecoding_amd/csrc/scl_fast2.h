@@ -421,6 +421,7 @@ struct Fast2Dec {
         uint32_t m_a = (uint32_t)b & 0xFFFFu, m_b = (uint32_t)(b >> 32) & 0xFFFFu;
         if (sizeof(R) == 8 && (__popc(m_a) != L || __popc(m_b) != L)) {
             // a key tie across the boundary (or a true median tie) in either codeword: decide on the full metrics
+            if (__popc(c ? m_b : m_a) != L) fl |= 0x4u;   // POLAR_FLAG_RERANK, this lane's codeword
             lds_fence();
             if (pos == 0) {
                 cand[p] = c0;

@@ -5,11 +5,12 @@
  * The transmit chain is the reference's, kept sequential on the host so that a fixed SEED reproduces the
  * published run counts: PN source (SCL_1024.c:184-197), CRC multiply by g(D) (CASCL_1024_L8.c:245-266),
  * u[I[i]] = w[i], x = u F^{(x)n} (:242-250, butterfly form), y = +-1 + n with n from Marsaglia polar on
- * Ranq1 (:295-326), std = 10^(-dB/20) (:226).  Frames are produced in order, decoded `batch` at a time
- * through polar_decode_batch_y (the kernel forms 2*y/std/std), and the reference's sequential stop rule
- * `for (run = 0; errBlock < BLE; run++)` (:228) is applied by cutting the batch at the frame of the BLE-th
- * block error and rewinding the generator state to just after that frame (RNG and PN phase carry over
- * SNR points exactly as in the reference, which never resets them).
+ * Ranq1 (:295-326), std = 10^(-dB/20) (:226).  Frames are produced in order and handed over `batch` at a time
+ * to polar_stop_rule_batch_y: the device decodes them (the kernel forms 2*y/std/std), compares with the sent
+ * bits and applies the reference's sequential stop rule `for (run = 0; errBlock < BLE; run++)` (:228) as a
+ * prefix count over its per-frame error counters; only (frames consumed, block errors, bit errors) come back.
+ * The generator state is rewound to just after the last consumed frame (RNG and PN phase carry over SNR points
+ * exactly as in the reference, which never resets them).
  *
  * Output lines follow the reference's printf formats (CASCL_1024_L8.c:308, SC_128.c:218-221).
  *
@@ -217,12 +218,25 @@ int main(int argc, char **argv)
     }
     c.A = K + c.r;
     c.sys = sys && c.r > 0;
-    (void)qfile;
+    /* --q file: N whitespace-separated positions in ascending reliability (the shape of the reference's `const int Q[N]`
+       literal, SC_1024.c:42-91); the information set is its last K + r entries, I[i] = Q[N-(K+r)+i] (CASCL_1024_L8.c:214-217) */
+    int *qorder = NULL;
+    if (qfile) {
+        FILE *fq = fopen(qfile, "r");
+        if (!fq) { fprintf(stderr, "cannot open %s\n", qfile); return 1; }
+        qorder = (int *)malloc(sizeof(int) * (size_t)N);
+        for (int i = 0; i < N; i++)
+            if (fscanf(fq, "%d", &qorder[i]) != 1 || qorder[i] < 0 || qorder[i] >= N) {
+                fprintf(stderr, "%s: need %d positions in [0, %d)\n", qfile, N, N);
+                return 1;
+            }
+        fclose(fq);
+    }
 
     polar_cfg cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.N = N; cfg.K = K; cfg.crc_r = c.r; cfg.crc_taps = c.r ? c.taps : NULL; cfg.n_taps = c.ntaps;
-    cfg.L = L; cfg.algo = algo; cfg.bp_iters = bp_iters; cfg.info_order = NULL; cfg.dtype = dtype; cfg.device = 0;
+    cfg.L = L; cfg.algo = algo; cfg.bp_iters = bp_iters; cfg.info_order = qorder ? qorder + (N - c.A) : NULL; cfg.dtype = dtype; cfg.device = 0;
     cfg.crc_systematic = c.sys;
     polar_ctx *ctx = NULL;
     int rc = polar_create(&cfg, &ctx);
@@ -236,11 +250,11 @@ int main(int argc, char **argv)
     gen_state g = {seed, 0, 0, 0};
     double *y = (double *)malloc(sizeof(double) * (size_t)batch * N);
     unsigned char *u = (unsigned char *)malloc((size_t)batch * N);
-    int *uh = (int *)malloc(sizeof(int) * (size_t)batch * N);
+    uint32_t *ubits = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)batch * (N / 32));
     gen_state *after = (gen_state *)malloc(sizeof(gen_state) * (size_t)batch);
     pair_t *pairs = (pair_t *)malloc(sizeof(pair_t) * (size_t)batch * (N / 2));
     int *mf = (int *)malloc(sizeof(int) * (size_t)batch);
-    if (!y || !u || !uh || !after || !pairs || !mf) { fprintf(stderr, "out of memory\n"); return 1; }
+    if (!y || !u || !ubits || !after || !pairs || !mf) { fprintf(stderr, "out of memory\n"); return 1; }
     printf("SEED = %llu\n", (unsigned long long)seed);
     if (fast) {
         unsigned long long first = 0;
@@ -271,19 +285,21 @@ int main(int argc, char **argv)
         memset(E, 0, sizeof E);
         while (errblock < ble) {
             make_batch(&g, &c, sigma, batch, u, y, after, pairs, mf);
-            rc = polar_decode_batch_y(ctx, y, sigma, (size_t)batch, uh, NULL, NULL);
-            if (rc) { fprintf(stderr, "decode: %s (%s)\n", polar_strerror(rc), polar_last_error(ctx)); return 1; }
-            int f;
-            for (f = 0; f < batch && errblock < ble; f++) { /* :296-305 */
-                int e = 0;
-                for (int i = c.sys ? c.r : 0; i < c.A; i++) { /* CASCL_1024_sys.c:820-821: payload bits only */
-                    const int j = c.I[i];
-                    e += (u[(size_t)f * N + j] != (unsigned char)uh[(size_t)f * N + j]);
-                }
-                errbit += e;
-                errblock += (e != 0);
-                run++;
+            for (size_t k = 0; k < (size_t)batch * (N / 32); k++) { /* sent bits, packed like the decisions */
+                uint32_t wd = 0;
+                for (int b = 0; b < 32; b++) wd |= (uint32_t)(u[k * 32 + b] & 1) << b;
+                ubits[k] = wd;
             }
+            /* decode + compare (:266-272) + stop rule (:228) on the device; the batch is cut WITH the frame that brings
+               the block errors to BLE */
+            size_t used = 0;
+            unsigned long long eb = 0, ebit = 0;
+            rc = polar_stop_rule_batch_y(ctx, y, sigma, ubits, (size_t)batch, (unsigned)(ble - errblock), &used, &eb, &ebit);
+            if (rc) { fprintf(stderr, "decode: %s (%s)\n", polar_strerror(rc), polar_last_error(ctx)); return 1; }
+            const int f = (int)used;
+            errblock += (int)eb;
+            errbit += (long)ebit;
+            run += (long)used;
             if (bpr) { /* read-outs of exactly the frames that count (BPr_128.c:417-565 runs inside BPr()) */
                 for (size_t k = 0; k < (size_t)f * N; k++) ui[k] = u[k];
                 rc = polar_bp_readout_batch(ctx, y, sigma, (size_t)f, ui, CP, 6, E, NULL);
@@ -313,6 +329,6 @@ int main(int argc, char **argv)
         fflush(stdout);
     }
     polar_destroy(ctx);
-    free(y); free(u); free(uh); free(after); free(c.I);
+    free(y); free(u); free(ubits); free(after); free(c.I); free(qorder);
     return 0;
 }

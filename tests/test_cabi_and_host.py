@@ -153,3 +153,24 @@ def test_two_rank_gloo_matches_single_process(oracle, tmp_path):
     for o, _ in outs:
         cl = [l for l in o.splitlines() if l.startswith("CUT")][0].split()
         assert tuple(int(x) for x in cl[2:]) == want
+
+
+def test_bench_launches_its_own_ranks_under_gloo():
+    """`python bench.py --gpus 2` with no launcher around it: the parent (which never touches a GPU) starts two ranks
+    through torch.distributed.run and relays rank 0's JSON line.  CPU rehearsal of that control path: gloo instead of
+    RCCL, nothing decoded (--rehearse-cpu), same barriers and reductions."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--rehearse-cpu"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 3 and d["rehearsal"] is True
+    assert d["counter_sum"] == [3, 30]          # (1 + 2, 10 + 20): the SUM all-reduce over both ranks
+    assert d["value"] is None                   # a rehearsal measures nothing
+    # a launcher that started a different number of ranks than --gpus says is an error, not a silent n_gpus = 1
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--rehearse-cpu"],
+                         capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0"))
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr

@@ -25,16 +25,19 @@ def _polar(u):
 
 
 @pytest.mark.parametrize("N,K,taps", [(1024, 512, (0, 1, 2, 4, 8, 12, 13, 15, 17, 20, 21, 23, 24)), (128, 64, (0, 5, 6)),
-                                      (1024, 512, None)])
+                                      (1024, 512, None), (64, 32, None), (64, 24, (0, 5, 6)), (256, 100, (0, 5, 6))])
 def test_generator_encoder_and_crc(N, K, taps):
     import torch
     import polardecoding_amd as pa
     dec = pa.CASCL(N, K, L=8, crc_taps=taps) if taps else pa.SCLdecode(N, K, L=8)
     B = 256
-    y = torch.empty(B, N, dtype=torch.float64, device="cuda")
+    GUARD = 4096                                              # the kernel must not write past frame B - 1
+    ybuf = torch.full((B * N + GUARD,), 12345.0, dtype=torch.float64, device="cuda")
+    y = ybuf[:B * N].view(B, N)
     ub = torch.empty(B, N // 32, dtype=torch.int32, device="cuda")
     dec.generate_device(7, 0, 40.0, y, ub, out_is_y=True)   # 40 dB: y = +-1 + 1e-2 noise
     dec.synchronize()
+    assert bool((ybuf[B * N:] == 12345.0).all()), "generator wrote beyond its output"
     u = _unpack(ub, N)
     io = dec.info_order
     frozen = np.ones(N, bool)

@@ -109,13 +109,12 @@ def test_config5_spilled_levels_vs_oracle(N, K, L, crc, oracle):
     assert np.array_equal(pm, ref_pm)
 
 
-def test_forced_spill_matches_golden(monkeypatch):
+def test_forced_spill_matches_golden():
     """The global-scratch variant on a shape that also fits LDS: same bits as the reference."""
     import polardecoding_amd as pa
-    monkeypatch.setenv("POLAR_FORCE_SPILL", "1")
-    monkeypatch.setenv("POLAR_FORCE_GENERIC", "1")
+    from polardecoding_amd import testing as T
     g = load_golden("CASCL_1024_L8")
-    dec = pa.CASCL(1024, 512, L=8)
+    dec = T.select_kernel(pa.CASCL(1024, 512, L=8), T.KERNEL_GENERIC_SPILL)
     assert "generic" in dec.kernel_name
     for s in np.unique(g["sigma"]):
         sel = g["sigma"] == s
@@ -147,14 +146,13 @@ def test_sc_one_codeword_per_lane_vs_oracle(N, K, B, dtype, oracle):
         assert np.array_equal(uh2, ref2)
 
 
-def test_big_list_kernel_matches_golden(monkeypatch):
+def test_big_list_kernel_matches_golden():
     """scl_big.h (low levels in LDS, the rest in scratch, lazily shared partial sums) forced onto the
     reference's own N = 1024 L = 8 programs: same bits and path metrics as the compiled reference."""
-    import polardecoding_amd as pa
-    monkeypatch.setenv("POLAR_FORCE_SPILL", "1")
+    from polardecoding_amd import testing as T
     for name in ("CASCL_1024_L8", "SCL_1024"):
         g = load_golden(name)
-        dec = make(name)
+        dec = T.select_kernel(make(name), T.KERNEL_BIG)
         assert "k_scl_big" in dec.kernel_name
         for s in np.unique(g["sigma"]):
             sel = g["sigma"] == s
@@ -165,9 +163,8 @@ def test_big_list_kernel_matches_golden(monkeypatch):
 
 @pytest.mark.parametrize("L", [2, 4, 16, 32])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_big_list_kernel_list_sizes_vs_oracle(L, dtype, oracle, monkeypatch):
+def test_big_list_kernel_list_sizes_vs_oracle(L, dtype, oracle):
     import polardecoding_amd as pa
-    monkeypatch.setenv("POLAR_FORCE_SPILL", "1")
     N, K = 1024, 512
     code = oracle.Code(N, K, pa.CRC24C_TAPS)
     sim = oracle.Sim(77 + L)
