@@ -125,15 +125,18 @@ int polar_count_errors_device(polar_ctx *ctx, const uint32_t *d_uhat_bits, const
  * The reference ends an Eb/N0 point WITH the frame that brings the block errors to BLE; generator state and PN phase
  * carry on from there.  For a batch decoded as a whole that is a prefix count over polar_count_errors_device's
  * d_frame_err, done on the device: d_out[0] = frames consumed (position of the `need`-th erroneous frame + 1, or B if
- * the batch holds fewer), d_out[1] / d_out[2] = block / bit errors among the consumed frames.  need >= 1. */
-int polar_stop_rule_cut_device(polar_ctx *ctx, const uint32_t *d_frame_err, size_t B, unsigned need,
+ * the batch holds fewer), d_out[1] / d_out[2] = block / bit errors among the consumed frames.
+ * min_frames: the rule behind the published L = 32 logs (myResult_1024.zip:CASCL_L32.dat, "error block = 487 run =
+ * 2000"), `errBlock < BLE || run < 2000`: consume at least min_frames frames (0 = the plain rule); with
+ * min_frames > 0, need may be 0 (BLE already reached, the minimum not yet). */
+int polar_stop_rule_cut_device(polar_ctx *ctx, const uint32_t *d_frame_err, size_t B, unsigned need, size_t min_frames,
                                unsigned long long *d_out /* [3] */);
 
 /* Host-buffer form, one iteration of main()'s loop over a batch: y [B][N] observations, sigma = std, u_bits [B][N/32]
  * the sent u packed like the decisions.  Decode, compare on the unfrozen positions (:266-272; payload only with
  * crc_systematic) and cut, all on the device; only three numbers come back. */
 int polar_stop_rule_batch_y(polar_ctx *ctx, const double *y, double sigma, const uint32_t *u_bits, size_t B,
-                            unsigned need, size_t *consumed, unsigned long long *block_errors,
+                            unsigned need, size_t min_frames, size_t *consumed, unsigned long long *block_errors,
                             unsigned long long *bit_errors);
 
 /* --- BP with per-stage read-outs (BPr_128.c:373-575: `BPr(y, u_hat, u)` and its table E[7][n+1]) -----------------

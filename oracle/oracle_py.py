@@ -267,13 +267,20 @@ def bp_readout(code, llr, u, iters, checkpoints):
     return uh, E
 
 
-def run_sweep(code, algo, snr_db, ble, seed, L=8, bp_iters=100):
+def run_sweep(code, algo, snr_db, ble, seed, L=8, bp_iters=100, min_run=0, want_blocks=False):
+    """min_run: the rule `errBlock < BLE || run < min_run` of the published L = 32 logs."""
     snr = np.asarray(snr_db, dtype=np.float64)
     run = (C.c_long * len(snr))()
     eb = (C.c_long * len(snr))()
-    rc = lib().po_run_sweep(code._h, ALGO[algo], L, bp_iters, seed, _dp(snr), len(snr), ble, run, eb)
+    blk = (C.c_long * len(snr))()
+    fn = lib().po_run_sweep_min
+    fn.argtypes = [C.POINTER(_Code), C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.c_int, C.c_int,
+                   C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    rc = fn(code._h, ALGO[algo], L, bp_iters, seed, _dp(snr), len(snr), ble, min_run, run, eb, blk)
     if rc != 0:
         raise RuntimeError(f"po_run_sweep rc={rc}")
+    if want_blocks:
+        return list(run), list(eb), list(blk)
     return list(run), list(eb)
 
 
@@ -291,6 +298,8 @@ REF_PROGRAMS = {
     "SC_1024": (1024, 512, None, "SC", 1),
     "BP_128": (128, 64, None, "BP", 1),
     "BP_1024": (1024, 512, None, "BP", 1),
+    # BP_1024.c with its `#define iterMax 100` reading 50 (BASELINE.json config 2; oracle/Makefile target ref50)
+    "BP_1024_it50": (1024, 512, None, "BP", 1),
     "SCL_128": (128, 64, None, "SCL", 8),
     "SCL_1024": (1024, 512, None, "SCL", 8),
     "CASCL_128": (128, 64, CRC6_TAPS, "CASCL", 8),
@@ -299,6 +308,7 @@ REF_PROGRAMS = {
     "CASCL_1024_sys": (1024, 512, CRC24C_TAPS, "CASCL", 8),
 }
 SYSTEMATIC_PROGRAMS = ("CASCL_1024_sys",)
+BP_ITERS = {"BP_128": 100, "BP_1024": 100, "BP_1024_it50": 50}   # iterMax, BP_1024.c:16
 
 
 def ref_available(name):

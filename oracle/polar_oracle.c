@@ -246,6 +246,12 @@ int po_count_bit_errors(const po_code *c, const int *u, const int *u_hat)
 int po_run_sweep(const po_code *c, int algo, int L, int bp_iters, uint64_t seed,
                  const double *snr_db, int n_snr, int ble, long *run_out, long *errbit_out)
 {
+    return po_run_sweep_min(c, algo, L, bp_iters, seed, snr_db, n_snr, ble, 0, run_out, errbit_out, NULL);
+}
+
+int po_run_sweep_min(const po_code *c, int algo, int L, int bp_iters, uint64_t seed, const double *snr_db, int n_snr,
+                     int ble, long min_run, long *run_out, long *errbit_out, long *errblock_out)
+{
     const int N = c->N;
     po_sim s;
     po_sim_init(&s, seed);
@@ -258,7 +264,7 @@ int po_run_sweep(const po_code *c, int algo, int L, int bp_iters, uint64_t seed,
         double sigma = po_sigma_from_db(snr_db[p]);
         long run = 0, errbit = 0;
         int errblock = 0;
-        for (run = 0; errblock < ble && rc == 0; run++) {
+        for (run = 0; (errblock < ble || run < min_run) && rc == 0; run++) {
             po_sim_frame(&s, c, sigma, u, y);
             po_llr_from_y(y, sigma, llr, N);
             switch (algo) {
@@ -274,6 +280,7 @@ int po_run_sweep(const po_code *c, int algo, int L, int bp_iters, uint64_t seed,
         }
         run_out[p] = run;
         if (errbit_out) errbit_out[p] = errbit;
+        if (errblock_out) errblock_out[p] = errblock;
     }
     free(u); free(uh); free(y); free(llr);
     return rc;

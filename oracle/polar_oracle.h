@@ -108,6 +108,12 @@ double po_sigma_from_db(double db);
 int po_run_sweep(const po_code *c, int algo, int L, int bp_iters, uint64_t seed,
                  const double *snr_db, int n_snr, int ble, long *run_out, long *errbit_out);
 
+/* The stop rule behind the published L = 32 logs (myResult_1024.zip:CASCL_L32.dat shows "error block = 487 run = 2000"):
+ * `errBlock < BLE || run < min_run`.  The sources in the repository have the plain rule (min_run = 0); the logs were
+ * made with a variant that is not in it.  errblock_out (nullable): block errors per point. */
+int po_run_sweep_min(const po_code *c, int algo, int L, int bp_iters, uint64_t seed, const double *snr_db, int n_snr,
+                     int ble, long min_run, long *run_out, long *errbit_out, long *errblock_out);
+
 /* CRC helpers (CASCL_1024_L8.c:245-266 encode, :569-598 check) */
 void po_crc_encode(const po_code *c, const int *v /*K*/, int *w /*A*/);
 int po_crc_check(const po_code *c, const int *w /*A*/);

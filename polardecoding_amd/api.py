@@ -69,6 +69,9 @@ def load_library():
     L.polar_decode_batch_y.argtypes = [vp, dp, C.c_double, C.c_size_t, ip, dp, up]
     L.polar_decode_device.argtypes = [vp, vp, C.c_int, C.c_double, C.c_size_t, vp, vp, vp]
     L.polar_count_errors_device.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
+    L.polar_stop_rule_cut_device.argtypes = [vp, vp, C.c_size_t, C.c_uint, C.c_size_t, vp]
+    L.polar_stop_rule_batch_y.argtypes = [vp, dp, C.c_double, vp, C.c_size_t, C.c_uint, C.c_size_t, C.POINTER(C.c_size_t),
+                                          C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.polar_bp_readout_device.argtypes = [vp, vp, C.c_int, C.c_double, C.c_size_t, vp, ip, C.c_int, vp, vp]
     L.polar_generate_device.argtypes = [vp, C.c_ulonglong, C.c_ulonglong, C.c_double, C.c_size_t, vp, C.c_int,
                                         C.c_int, vp]
@@ -246,6 +249,25 @@ class Decoder:
             self._h, C.c_void_p(uhat_bits.data_ptr()), C.c_void_p(u_bits.data_ptr()), B,
             C.c_void_p(counters.data_ptr()),
             C.c_void_p(frame_err.data_ptr()) if frame_err is not None else None), "polar_count_errors_device")
+
+    def stop_rule_cut_device(self, frame_err, need, out, min_frames=0):
+        """The reference's sequential stop rule (SCL_1024.c:228) on the per-frame error counts of a batch: out (int64
+        CUDA tensor [3]) <- frames consumed, block errors, bit errors among them.  Asynchronous on the ctx stream."""
+        self._check(self._lib.polar_stop_rule_cut_device(self._h, C.c_void_p(frame_err.data_ptr()), frame_err.numel(),
+                                                         int(need), int(min_frames), C.c_void_p(out.data_ptr())),
+                    "polar_stop_rule_cut_device")
+
+    def stop_rule_batch_y(self, y, sigma, u, need, min_frames=0):
+        """One batch of main()'s loop on host buffers: y [B][N] observations, u [B][N] sent bits (0/1).  Returns
+        (frames consumed, block errors, bit errors) under the stop rule with `need` block errors still missing."""
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1, self.N)
+        ub = np.packbits(np.ascontiguousarray(u, dtype=np.uint8).reshape(-1, self.N), axis=1, bitorder="little")
+        ub = np.ascontiguousarray(ub).view(np.uint32)
+        used, blk, bits = C.c_size_t(0), C.c_ulonglong(0), C.c_ulonglong(0)
+        self._check(self._lib.polar_stop_rule_batch_y(self._h, _ptr(y, C.c_double), float(sigma), ub.ctypes.data, y.shape[0],
+                                                      int(need), int(min_frames), C.byref(used), C.byref(blk), C.byref(bits)),
+                    "polar_stop_rule_batch_y")
+        return used.value, blk.value, bits.value
 
     def bp_readout_device(self, d_in, u_bits, checkpoints, E, out_bits=None, sigma=0.0):
         """BPr_128.c: BP with per-stage read-outs.  d_in [B][N] LLR (or y with sigma), u_bits [B][N/32] int32 sent

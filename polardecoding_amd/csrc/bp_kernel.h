@@ -385,16 +385,19 @@ __global__ __launch_bounds__(256) void k_count_errors(CountParams P)
 // is a prefix count over the per-frame error counts k_count_errors wrote: out[0] = frames consumed (index of the
 // `need`-th erroneous frame + 1, or B if the batch does not contain that many), out[1] / out[2] = block / bit
 // errors among the consumed frames.  One workgroup: B words are read twice, which is nothing next to the decode.
-__global__ __launch_bounds__(1024) void k_stop_cut(const uint32_t *frame_err, int B, unsigned need, unsigned long long *out)
+// min_frames: the variant behind the published L = 32 logs (myResult_1024.zip:CASCL_L32.dat: "run = 2000" with 487
+// block errors), `errBlock < BLE || run < 2000`: at least that many frames are consumed; need may then be 0.
+__global__ __launch_bounds__(1024) void k_stop_cut(const uint32_t *frame_err, int B, unsigned need, int min_frames,
+                                                   unsigned long long *out)
 {
     __shared__ unsigned wcnt[16];
     __shared__ unsigned long long wbits[16];
     __shared__ unsigned base_s;
     __shared__ int cut_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) { base_s = 0; cut_s = B; }
+    if (tid == 0) { base_s = 0; cut_s = need ? B : 0; }
     __syncthreads();
-    for (int s0 = 0; s0 < B; s0 += 1024) {   // pass 1: where is the need-th erroneous frame?
+    for (int s0 = 0; need && s0 < B; s0 += 1024) {   // pass 1: where is the need-th erroneous frame?
         const int f = s0 + tid;
         const bool bad = f < B && frame_err[f] != 0;
         const unsigned long long m = __ballot(bad);
@@ -413,7 +416,8 @@ __global__ __launch_bounds__(1024) void k_stop_cut(const uint32_t *frame_err, in
         __syncthreads();
         if (cut_s != B || base_s >= need) break;   // uniform: both are shared and were written before the barrier
     }
-    const int cut = cut_s;
+    const bool found = need == 0 || base_s >= need;
+    const int cut = found ? min(B, max(cut_s, min_frames)) : B;
     unsigned blk = 0;
     unsigned long long bits = 0;
     for (int f = tid; f < cut; f += 1024) {   // pass 2: the counters over the consumed frames

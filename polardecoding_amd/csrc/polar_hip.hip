@@ -930,23 +930,27 @@ int polar_count_errors_device(polar_ctx *c, const uint32_t *d_uhat, const uint32
     return POLAR_OK;
 }
 
-int polar_stop_rule_cut_device(polar_ctx *c, const uint32_t *d_frame_err, size_t B, unsigned need, unsigned long long *d_out)
+int polar_stop_rule_cut_device(polar_ctx *c, const uint32_t *d_frame_err, size_t B, unsigned need, size_t min_frames,
+                               unsigned long long *d_out)
 {
-    if (!c || !d_frame_err || !d_out || need < 1 || B > 0x7fffffffull) return POLAR_EINVAL;
+    if (!c || !d_frame_err || !d_out || (need < 1 && min_frames < 1) || B > 0x7fffffffull) return POLAR_EINVAL;
     DeviceGuard guard(c->cfg.device);
     if (B == 0) {
         HIP_TRY(c, hipMemsetAsync(d_out, 0, 3 * sizeof(unsigned long long), c->stream));
         return POLAR_OK;
     }
-    hipLaunchKernelGGL(polar::k_stop_cut, dim3(1), dim3(1024), 0, c->stream, d_frame_err, (int)B, need, d_out);
+    hipLaunchKernelGGL(polar::k_stop_cut, dim3(1), dim3(1024), 0, c->stream, d_frame_err, (int)B, need,
+                       (int)std::min<size_t>(min_frames, B), d_out);
     HIP_TRY(c, hipGetLastError());
     return POLAR_OK;
 }
 
 int polar_stop_rule_batch_y(polar_ctx *c, const double *y, double sigma, const uint32_t *u_bits, size_t B, unsigned need,
-                            size_t *consumed, unsigned long long *block_errors, unsigned long long *bit_errors)
+                            size_t min_frames, size_t *consumed, unsigned long long *block_errors,
+                            unsigned long long *bit_errors)
 {
-    if (!c || !y || !u_bits || !consumed || !block_errors || !bit_errors || need < 1 || !(sigma > 0)) return POLAR_EINVAL;
+    if (!c || !y || !u_bits || !consumed || !block_errors || !bit_errors || (need < 1 && min_frames < 1) || !(sigma > 0))
+        return POLAR_EINVAL;
     *consumed = 0; *block_errors = 0; *bit_errors = 0;
     if (B == 0) return POLAR_OK;
     if (B > 0x7fffffffull) return POLAR_EINVAL;
@@ -965,7 +969,7 @@ int polar_stop_rule_batch_y(polar_ctx *c, const double *y, double sigma, const u
     if ((rc = decode_device_impl(c, c->in.p, 0, sigma, B, (uint32_t *)c->bits.p, nullptr, nullptr, c->d_frozen))) return rc;
     if ((rc = polar_count_errors_device(c, (uint32_t *)c->bits.p, (uint32_t *)c->gen_u.p, B, cnt, (uint32_t *)c->flags.p)))
         return rc;
-    if ((rc = polar_stop_rule_cut_device(c, (uint32_t *)c->flags.p, B, need, cnt + 2))) return rc;
+    if ((rc = polar_stop_rule_cut_device(c, (uint32_t *)c->flags.p, B, need, min_frames, cnt + 2))) return rc;
     unsigned long long h[3];
     HIP_TRY(c, hipMemcpyAsync(h, cnt + 2, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

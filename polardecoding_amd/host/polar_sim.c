@@ -168,7 +168,7 @@ static const int CRC6[] = {0, 5, 6};
 static void usage(void)
 {
     fprintf(stderr, "usage: polar_sim --algo sc|bp|bpr|scl|cascl --N n --K k [--L l] [--crc 24c|6] [--sys] [--seed s] [--ble b]\n"
-                    "                 [--snr lo:hi:step] [--batch b] [--dtype f64|f32] [--bp-iters i] [--q file]\n");
+                    "                 [--snr lo:hi:step | --snr-list a,b,..] [--batch b] [--dtype f64|f32] [--bp-iters i] [--q file] [--min-run m] [--fast]\n");
     exit(2);
 }
 
@@ -176,8 +176,11 @@ int main(int argc, char **argv)
 {
     int N = 1024, K = 512, L = 8, algo = POLAR_ALGO_CASCL, ble = 100, batch = 4096, dtype = POLAR_F64, bp_iters = 100;
     int fast = 0, sys = 0, bpr = 0;
+    long min_run = 0;   /* --min-run m: `errBlock < BLE || run < m`, the rule of the published L = 32 logs (m = 2000) */
     uint64_t seed = 1024;
     double lo = 1.0, hi = 3.0, step = 0.5;
+    double pts[64];
+    int npts = 0;   /* --snr-list a,b,c: explicit Eb/N0 points (the published L = 32 log goes 1.0, 1.5, 2.0, 2.2) */
     const char *crc = NULL, *qfile = NULL;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -197,15 +200,27 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--batch") && v) { batch = atoi(v); i++; }
         else if (!strcmp(a, "--bp-iters") && v) { bp_iters = atoi(v); i++; }
         else if (!strcmp(a, "--q") && v) { qfile = v; i++; }
+        else if (!strcmp(a, "--min-run") && v) { min_run = atol(v); i++; }
         else if (!strcmp(a, "--fast")) { fast = 1; }
         else if (!strcmp(a, "--sys")) { sys = 1; }
         else if (!strcmp(a, "--dtype") && v) { dtype = !strcmp(v, "f32") ? POLAR_F32 : POLAR_F64; i++; }
-        else if (!strcmp(a, "--snr") && v) {
+        else if (!strcmp(a, "--snr-list") && v) {
+            const char *q = v;
+            while (*q && npts < 64) {
+                char *end;
+                pts[npts++] = strtod(q, &end);
+                if (end == q) usage();
+                q = (*end == ',') ? end + 1 : end;
+            }
+            i++;
+        } else if (!strcmp(a, "--snr") && v) {
             if (sscanf(v, "%lf:%lf:%lf", &lo, &hi, &step) != 3) usage();
             i++;
         } else usage();
     }
     if (N > 4096 || N < 32) usage();
+    if (npts == 0)
+        for (double db = lo; db <= hi + 1e-12 && npts < 64; db += step) pts[npts++] = db;   /* SCL_1024.c:223 */
     code_t c;
     memset(&c, 0, sizeof c);
     c.N = N; c.K = K;
@@ -258,7 +273,8 @@ int main(int argc, char **argv)
     printf("SEED = %llu\n", (unsigned long long)seed);
     if (fast) {
         unsigned long long first = 0;
-        for (double db = lo; db <= hi + 1e-12; db += step) {
+        for (int ip = 0; ip < npts; ip++) {
+            const double db = pts[ip];
             unsigned long long blk = 0, bits = 0, run = 0;
             while (blk < (unsigned long long)ble) {
                 rc = polar_fer_batch(ctx, seed, first, db, (size_t)batch, &blk, &bits);
@@ -277,13 +293,14 @@ int main(int argc, char **argv)
     int *ui = bpr ? (int *)malloc(sizeof(int) * (size_t)batch * N) : NULL;
     int nlog = 0;
     while ((1 << nlog) < N) nlog++;
-    for (double db = lo; db <= hi + 1e-12; db += step) {
+    for (int ip = 0; ip < npts; ip++) {
+        const double db = pts[ip];
         const double sigma = pow(10, db / ((double)-20)); /* :226 */
         long run = 0, errbit = 0;
         int errblock = 0;
         unsigned long long E[6 * 16];
         memset(E, 0, sizeof E);
-        while (errblock < ble) {
+        while (errblock < ble || run < min_run) {
             make_batch(&g, &c, sigma, batch, u, y, after, pairs, mf);
             for (size_t k = 0; k < (size_t)batch * (N / 32); k++) { /* sent bits, packed like the decisions */
                 uint32_t wd = 0;
@@ -294,7 +311,8 @@ int main(int argc, char **argv)
                the block errors to BLE */
             size_t used = 0;
             unsigned long long eb = 0, ebit = 0;
-            rc = polar_stop_rule_batch_y(ctx, y, sigma, ubits, (size_t)batch, (unsigned)(ble - errblock), &used, &eb, &ebit);
+            rc = polar_stop_rule_batch_y(ctx, y, sigma, ubits, (size_t)batch, (unsigned)(errblock < ble ? ble - errblock : 0),
+                                         (size_t)(run < min_run ? min_run - run : 0), &used, &eb, &ebit);
             if (rc) { fprintf(stderr, "decode: %s (%s)\n", polar_strerror(rc), polar_last_error(ctx)); return 1; }
             const int f = (int)used;
             errblock += (int)eb;
@@ -305,7 +323,7 @@ int main(int argc, char **argv)
                 rc = polar_bp_readout_batch(ctx, y, sigma, (size_t)f, ui, CP, 6, E, NULL);
                 if (rc) { fprintf(stderr, "readout: %s (%s)\n", polar_strerror(rc), polar_last_error(ctx)); return 1; }
             }
-            if (errblock >= ble) g = after[f - 1]; /* rewind to just after the frame that hit the stop rule */
+            if (errblock >= ble && run >= min_run) g = after[f - 1]; /* rewind to just after the frame that ended the point */
         }
         if (bpr) { /* BPr_128.c:227-258 */
             printf("bSNR = %.2lf\terror block = %d\trun = %ld\t", db, errblock, run);

@@ -63,6 +63,31 @@ def test_published_run_counts(key, seed, L, n, args):
     assert got == exp, text
 
 
+def _l32_cases():
+    out = []
+    for key, N, K, crc in (("myResult_1024/CASCL_L32.dat", 1024, 512, "24c"), ("myResult_128/CASCL_128_L32.txt", 128, 64, "6")):
+        for b in PUB[key]:
+            out.append(pytest.param(key, N, K, crc, b, id=f"{key.split('/')[1]}-s{b['seed']}"))
+    return out
+
+
+@pytest.mark.parametrize("key,N,K,crc,blk", _l32_cases())
+def test_published_L32_logs_with_their_min_run_rule(key, N, K, crc, blk):
+    """CA-SCL at L = 32 on reference-held data: myResult_1024.zip:CASCL_L32.dat (six seeds, CRC-24C, to 2.2 dB:
+    430-590 k frames each) and myResult_128.zip:CASCL_128_L32.txt (two seeds, CRC-6, to 3.5 dB: 1.05 M frames each).
+    These logs were made with `errBlock < BLE || run < 2000` ("error block = 487 run = 2000"), not the rule in the
+    repository's sources; polar_sim --min-run 2000 reproduces every run count AND every block-error count."""
+    assert os.path.exists(SIM), "polar_sim not built (run __graft_entry__.build())"
+    rows = blk["rows"]
+    args = ["--algo", "cascl", "--N", str(N), "--K", str(K), "--L", str(blk["L"]), "--crc", crc, "--seed", str(blk["seed"]),
+            "--ble", str(blk["ble"]), "--min-run", str(blk["min_run"]), "--snr-list", ",".join(str(r[0]) for r in rows),
+            "--batch", "8192"]
+    out = subprocess.run([SIM] + args, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = [(int(a), int(b)) for a, b in re.findall(r"error block = (\d+)\s+run = (\d+)", out.stdout)]
+    assert got == [(r[1], r[2]) for r in rows], out.stdout
+
+
 def test_systematic_program_run_counts(oracle):
     """CASCL_1024_sys.c (systematic CRC, K-bit error metric) has no published log; its run counts come from the
     oracle, whose decoder matches the compiled program on the fixtures and whose generator rows were compared with
@@ -86,3 +111,17 @@ def test_bpr_main_output_reproduced():
                           "--snr", "1.0:2.0:0.5", "--batch", "256"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout == exp, out.stdout[:3000]
+
+
+def test_reliability_order_from_a_file(tmp_path):
+    """--q file (the shape of the reference's `const int Q[N]` literal): the 5G order handed in as a file gives the run
+    counts of the built-in table."""
+    import polardecoding_amd as pa
+    q = tmp_path / "q128.txt"
+    q.write_text(" ".join(str(x) for x in pa.q_sequence(128)) + "\n")
+    base = ["--algo", "cascl", "--N", "128", "--K", "64", "--L", "8", "--crc", "6", "--snr", "1.0:2.0:0.5", "--seed", "8392",
+            "--ble", "200", "--batch", "512"]
+    a, _ = run_sim(base)
+    b, _ = run_sim(base + ["--q", str(q)])
+    exp, _ = published("myResult_128/CASCL_128_L8.txt", 8392, 8, 3)
+    assert a == b == exp

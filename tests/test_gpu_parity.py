@@ -13,6 +13,7 @@ PROGRAMS = {
     "SC_1024": (1024, 512, "SCdecode", {}),
     "BP_128": (128, 64, "BP", {"iterMax": 100}),
     "BP_1024": (1024, 512, "BP", {"iterMax": 100}),
+    "BP_1024_it50": (1024, 512, "BP", {"iterMax": 50}),   # BASELINE config 2's count; fixture from BP_1024.c compiled with iterMax 50
     "SCL_128": (128, 64, "SCLdecode", {"L": 8}),
     "SCL_1024": (1024, 512, "SCLdecode", {"L": 8}),
     "CASCL_128": (128, 64, "CASCL", {"L": 8, "crc_taps": (0, 5, 6)}),

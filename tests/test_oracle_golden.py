@@ -5,7 +5,7 @@ import pytest
 
 from conftest import load_golden
 
-PROGRAMS = ["SC_128", "SC_1024", "BP_128", "BP_1024", "SCL_128", "SCL_1024", "CASCL_128", "CASCL_1024_L8",
+PROGRAMS = ["SC_128", "SC_1024", "BP_128", "BP_1024", "BP_1024_it50", "SCL_128", "SCL_1024", "CASCL_128", "CASCL_1024_L8",
             "CASCL_1024_sys"]  # the last one decodes on the bit-reversed graph: same decisions
 
 
@@ -17,7 +17,7 @@ def test_oracle_matches_golden(name, oracle):
     n = len(g["sigma"]) if N == 128 or algo != "BP" else 4
     for i in range(n):
         llr = oracle.llr_from_y(g["y"][i], float(g["sigma"][i]))
-        uh, pm, ties = oracle.decode(code, llr, algo, L=L, bp_iters=100)
+        uh, pm, ties = oracle.decode(code, llr, algo, L=L, bp_iters=oracle.BP_ITERS.get(name, 100))
         assert np.array_equal(uh, g["u_hat"][i].astype(np.int32)), f"{name} frame {i}"
         if algo in ("SCL", "CASCL"):
             assert pm == g["pm"][i]
@@ -40,7 +40,7 @@ def test_oracle_matches_compiled_reference(name, oracle):
         for _ in range(nfr):
             u, y = sim.frame(code, s)
             uh_ref, pm_ref = ref.decode(y, s)
-            uh, pm, _ = oracle.decode(code, oracle.llr_from_y(y, s), algo, L=L, bp_iters=100)
+            uh, pm, _ = oracle.decode(code, oracle.llr_from_y(y, s), algo, L=L, bp_iters=oracle.BP_ITERS.get(name, 100))
             assert np.array_equal(uh, uh_ref)
             if algo in ("SCL", "CASCL"):
                 assert pm == pm_ref

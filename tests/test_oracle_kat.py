@@ -53,3 +53,24 @@ def test_scl1024(oracle, L, npts):
 @pytest.mark.parametrize("seed", [1242, 5139])
 def test_cascl1024_crc24(oracle, seed):
     check(oracle, oracle.Code(1024, 512, oracle.CRC24C_TAPS), "CASCL", "myResult_1024/CASCL_L8.dat", seed, 8, 2)
+
+
+# ---- CA-SCL at L = 32: logs made with `errBlock < BLE || run < 2000` (they show "error block = 487 run = 2000"),
+# a rule the sources in the repository do not have; with it the restated harness reproduces them ----
+
+def check_min_run(oracle, code, key, seed, npoints):
+    b = [x for x in PUB[key] if x["seed"] == seed][0]
+    r = b["rows"][:npoints]
+    run, _, blk = oracle.run_sweep(code, "CASCL", [x[0] for x in r], b["ble"], seed, L=b["L"], min_run=b["min_run"],
+                                   want_blocks=True)
+    assert run == [x[2] for x in r] and blk == [x[1] for x in r], f"{key} seed {seed}"
+
+
+@pytest.mark.parametrize("seed", [2525, 7092])
+def test_cascl128_crc6_L32_published(oracle, seed):
+    check_min_run(oracle, oracle.Code(128, 64, oracle.CRC6_TAPS), "myResult_128/CASCL_128_L32.txt", seed, 2)
+
+
+def test_cascl1024_crc24_L32_published(oracle):
+    # two points = 4000 frames at L = 32 (25 s); every seed to its last point runs on the GPU (tests/test_gpu_kat.py)
+    check_min_run(oracle, oracle.Code(1024, 512, oracle.CRC24C_TAPS), "myResult_1024/CASCL_L32.dat", 1825, 2)
