@@ -13,7 +13,17 @@
 /* I[i] = Q[N-(K+r)+i], inI[I[i]] = 1 (CASCL_1024_L8.c:209-217; SCL_1024.c:198-206 with r = 0) */
 po_code *po_code_create(int N, int K, int r, const int *taps, int ntaps, const int *Q)
 {
-    if (N < 2 || (N & (N - 1)) || K < 1 || r < 0 || K + r > N || ntaps > PO_MAX_TAPS) return NULL;
+    return po_code_create_q(N, K, r, taps, ntaps, Q, N);
+}
+
+/* qlen = number of entries Q really has: the 5G table stops at 1024 and a caller asking for N = 2048 with it used to
+ * walk off its end.  Every position taken from Q is checked (range, listed once). */
+po_code *po_code_create_q(int N, int K, int r, const int *taps, int ntaps, const int *Q, int qlen)
+{
+    if (N < 2 || (N & (N - 1)) || K < 1 || r < 0 || K + r > N || ntaps > PO_MAX_TAPS || ntaps < 0) return NULL;
+    if (!Q || qlen < N || (r > 0 && (!taps || ntaps < 2))) return NULL;
+    for (int i = 0; i < (r > 0 ? ntaps : 0); i++)
+        if (taps[i] < 0 || taps[i] > r) return NULL;
     po_code *c = (po_code *)calloc(1, sizeof(po_code));
     if (!c) return NULL;
     c->N = N;
@@ -29,8 +39,10 @@ po_code *po_code_create(int N, int K, int r, const int *taps, int ntaps, const i
     if (!c->info_order || !c->frozen) { po_code_destroy(c); return NULL; }
     memset(c->frozen, 1, (size_t)N);
     for (int i = 0; i < c->A; i++) {
-        c->info_order[i] = Q[N - c->A + i];
-        c->frozen[c->info_order[i]] = 0;
+        const int j = Q[N - c->A + i];
+        if (j < 0 || j >= N || c->frozen[j] == 0) { po_code_destroy(c); return NULL; }
+        c->info_order[i] = j;
+        c->frozen[j] = 0;
     }
     return c;
 }
@@ -113,11 +125,18 @@ void po_polar_encode(int N, const int *u, int *x)
 /* ---- decoders: generic bodies ------------------------------------------------------------- */
 
 /* statistics of the last po_scl_decode_* call (test instrumentation, see polar_oracle_impl.h) */
-static __thread int po_last_key_fallbacks, po_last_triples;
+static __thread int po_last_key_fallbacks, po_last_triples, po_last_phase2, po_last_trivial;
 void po_scl_last_stats(int *out)
 {
     out[0] = po_last_key_fallbacks;
     out[1] = po_last_triples;
+}
+/* out[0] = information leaves decided with a full list, out[1] = those where every path just keeps its better branch
+ * and the 32-bit keys show it (max of the better keys < min of the worse keys) */
+void po_scl_last_prune_stats(int *out)
+{
+    out[0] = po_last_phase2;
+    out[1] = po_last_trivial;
 }
 
 #define REAL double

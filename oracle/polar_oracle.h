@@ -44,6 +44,8 @@ typedef struct po_code {
 /* Code construction (CASCL_1024_L8.c:209-217; SCL_1024.c:198-206).  Q = ascending-reliability
  * sequence restricted to < N (length N).  taps may be NULL when r == 0. */
 po_code *po_code_create(int N, int K, int r, const int *taps, int ntaps, const int *Q);
+/* same with the real length of Q stated (NULL if qlen < N); positions are range- and duplicate-checked in both */
+po_code *po_code_create_q(int N, int K, int r, const int *taps, int ntaps, const int *Q, int qlen);
 void po_code_destroy(po_code *c);
 /* CASCL_1024_sys.c: systematic CRC encoding and the K-true-info-bit error metric (:820-821).  The decoder
  * itself is unchanged: that program's bit-reversed graph with y[bRev[j]] on channel row j is the natural graph

@@ -291,6 +291,8 @@ int FN(po_scl_decode)(const po_code *c, const REAL *llr, int L, int crc, int *u_
     int act = 1;
     po_last_key_fallbacks = 0;
     po_last_triples = 0;
+    po_last_phase2 = 0;
+    po_last_trivial = 0;
     PM[0] = 0; /* SCL_1024.c:556 */
     for (int j = 0; j < N; j++) {
         for (int k = 0; k < act; k++) lam[k] = FN(scl_leaf_llr)(&w, llr, k, j);
@@ -324,6 +326,16 @@ int FN(po_scl_decode)(const po_code *c, const REAL *llr, int L, int crc, int *u_
                     keep += (cnt <= L);
                 }
                 if (keep != L) po_last_key_fallbacks++;
+                /* leaves where every path simply keeps its better branch, decided on the 32-bit keys alone */
+                uint32_t mx = 0, mn = 0xffffffffu;
+                for (int a = 0; a < L; a++) {
+                    uint32_t k0 = FN(key32)(cand[a]), k1 = FN(key32)(cand[a + L]);
+                    uint32_t lo = k0 < k1 ? k0 : k1, hi = k0 < k1 ? k1 : k0;
+                    if (lo > mx) mx = lo;
+                    if (hi < mn) mn = hi;
+                }
+                po_last_phase2++;
+                if (mx < mn) po_last_trivial++;
             }
             qsort(cand, (size_t)2 * L, sizeof(REAL), FN(cmp_real)); /* QuickSort, :619 */
             REAL med = cand[L];

@@ -79,6 +79,7 @@ struct Fast2Dec {
     int logact;
     int p, c, pos, lane, gl;   // gl = c*4 + pos: lane offset inside a path group
     int own_addr, oth_addr;    // rank network: byte addresses into keys[]
+    uint32_t pos0_mask;        // ~0 in the lane that holds its path's metric (pos 0), else 0
     int cand_addr;
     Lut<R> lut;
     R *cand, *stg;
@@ -441,6 +442,31 @@ struct Fast2Dec {
         return c ? m_b : m_a;
     }
 
+    // ---- "every path keeps its better branch" (see decide): true if so for BOTH codewords; bit = that branch ----
+    __device__ __forceinline__ bool trivial_prune(R c0, R c1, uint32_t &bit) const
+    {
+        const uint32_t k0 = metric_key(c0), k1 = metric_key(c1);
+        // metrics are valid at pos 0; the other lanes of a path take no part (0 for the max, ~0 for the min)
+        uint32_t mx = min(k0, k1) & pos0_mask, mn = max(k0, k1) | ~pos0_mask;
+        mx = max(mx, (uint32_t)dpp_i<0x128>((int)mx));   // row_ror:8: the other path of this row of 16 lanes
+        mn = min(mn, (uint32_t)dpp_i<0x128>((int)mn));
+        {
+            auto a = __builtin_amdgcn_permlane16_swap(mx, mx, false, false);
+            auto b = __builtin_amdgcn_permlane16_swap(mn, mn, false, false);
+            mx = max(a[0], a[1]);
+            mn = min(b[0], b[1]);
+        }
+        {
+            auto a = __builtin_amdgcn_permlane32_swap(mx, mx, false, false);
+            auto b = __builtin_amdgcn_permlane32_swap(mn, mn, false, false);
+            mx = max(a[0], a[1]);
+            mn = min(b[0], b[1]);
+        }
+        if (__ballot(mx >= mn) != 0ull) return false;
+        bit = (uint32_t)dpp_i<0x00>((int)(k1 < k0 ? 1u : 0u));   // quad_perm [0,0,0,0]: pos 0 decides for its path
+        return true;
+    }
+
     // ---- decision at leaf j = 8o + K; lambda valid at pos 0 ----
     template <int K>
     __device__ __forceinline__ void decide(int o, bool frozen, R lam)
@@ -463,6 +489,14 @@ struct Fast2Dec {
             } else {
                 POLAR_MARK("d2_phase2");
                 const R c0 = PM + ph0, c1 = PM + ph1;
+                // Most information leaves (85 % at 1-3 dB) prune trivially: every path keeps its better branch.  That
+                // is certain when the largest of the eight smaller keys is below the smallest of the eight larger
+                // keys (the 8 smaller candidates are then the 8 smallest of the 16, all strictly below the median of
+                // SCL_1024.c:619-633), and three max/min steps over the path lanes show it -- without the key
+                // exchange through LDS, the rank network and the fork bookkeeping.  Both codewords must qualify.
+                if (trivial_prune(c0, c1, bit)) {
+                    PM = bit ? c1 : c0;
+                } else {
                 const uint32_t mask = survivors(c0, c1);
                 POLAR_MARK("d2_rank_end");
                 const uint32_t m0 = mask & 0xFFu, m1 = mask >> 8;
@@ -491,6 +525,7 @@ struct Fast2Dec {
                     else if (s0) { bit = 0; PM = c0; }
                     else if (s1) { bit = 1; PM = c1; }
                     else { bit = 0; PM = c0; }  // tie rule: un-refilled dead slot continues as its 0-branch
+                }
                 }
             }
             POLAR_MARK("d2_fork_end");
@@ -682,6 +717,7 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
     s.p = s.lane >> 3;
     s.c = (s.lane >> 2) & 1;
     s.pos = s.lane & 3;
+    s.pos0_mask = s.pos == 0 ? 0xFFFFFFFFu : 0u;
     s.gl = s.lane & 7;
     s.lut.bind(smem + C::off_lut);
     s.crct = crct;

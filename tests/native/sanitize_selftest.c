@@ -1,0 +1,173 @@
+/*
+ * sanitize_selftest.c -- the CPU-side C code of this repository under AddressSanitizer + UBSan (SURVEY.md 5,
+ * "race detection / sanitizers"; the GPU pool has no device sanitizer).  TEST INFRASTRUCTURE: built by
+ * `make -C oracle asan`, run by tests/test_sanitizers.py.
+ *
+ * Covers (a) the oracle: every decoder, the literal model, the harness, the CRC helpers, code construction with bad
+ * arguments; (b) the generator half of the C host harness polardecoding_amd/host/polar_sim.c (PN, CRC, encoder, the
+ * split sequential/parallel noise generator), which is compared here with the oracle's statement of the same chain.
+ * polar_sim.c is compiled in with its main() renamed; the GPU entry points it would call are never reached here and
+ * are given link-time placeholders.
+ */
+#define main polar_sim_main
+#include "../../polardecoding_amd/host/polar_sim.c"
+#undef main
+
+#include "../../oracle/polar_oracle.h"
+
+/* never called by this program */
+int polar_create(const polar_cfg *a, polar_ctx **b) { (void)a; (void)b; return POLAR_EDEVICE; }
+void polar_destroy(polar_ctx *a) { (void)a; }
+const char *polar_strerror(int a) { (void)a; return ""; }
+const char *polar_last_error(const polar_ctx *a) { (void)a; return ""; }
+int polar_info_order(const polar_ctx *a, int *b, int c) { (void)a; (void)b; (void)c; return POLAR_EDEVICE; }
+int polar_fer_batch(polar_ctx *a, unsigned long long b, unsigned long long c, double d, size_t e, unsigned long long *f,
+                    unsigned long long *g) { (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; return POLAR_EDEVICE; }
+int polar_stop_rule_batch_y(polar_ctx *a, const double *b, double c, const uint32_t *d, size_t e, unsigned f, size_t g,
+                            size_t *h, unsigned long long *i, unsigned long long *j)
+{ (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; (void)j; return POLAR_EDEVICE; }
+int polar_bp_readout_batch(polar_ctx *a, const double *b, double c, size_t d, const int *e, const int *f, int g,
+                           unsigned long long *h, int *i)
+{ (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; return POLAR_EDEVICE; }
+
+static int fails = 0;
+#define CHECK(cond, what) do { if (!(cond)) { fprintf(stderr, "FAIL: %s (%s:%d)\n", what, __FILE__, __LINE__); fails++; } } while (0)
+
+/* 5G reliability order restricted to < N, from the data file the library itself is built from */
+static int *load_q(const char *path, int N)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+    int *q = (int *)malloc(sizeof(int) * (size_t)N), cnt = 0, v;
+    char line[4096];
+    while (fgets(line, sizeof line, f)) {
+        if (line[0] == '#') continue;
+        char *p = line, *e;
+        for (;;) {
+            v = (int)strtol(p, &e, 10);
+            if (e == p) break;
+            p = e;
+            if (v < N && cnt < N) q[cnt++] = v;
+        }
+    }
+    fclose(f);
+    if (cnt != N) { fprintf(stderr, "%s: %d entries below %d\n", path, cnt, N); exit(2); }
+    return q;
+}
+
+static void generator_against_oracle(const int *Q, int N, int K, int r, const int *taps, int ntaps, int sys, uint64_t seed)
+{
+    po_code *pc = po_code_create(N, K, r, taps, ntaps, Q);
+    CHECK(pc != NULL, "po_code_create");
+    if (!pc) return;
+    po_code_set_systematic(pc, sys);
+    code_t c;
+    memset(&c, 0, sizeof c);
+    c.N = N; c.K = K; c.r = r; c.A = K + r; c.ntaps = r ? ntaps : 0; c.sys = sys && r > 0;
+    for (int i = 0; i < c.ntaps; i++) c.taps[i] = taps[i];
+    c.I = pc->info_order;
+    const int batch = 200;   /* > 64 * 3: several helper threads in make_batch */
+    gen_state g = {seed, 0, 0, 0};
+    po_sim s;
+    po_sim_init(&s, seed);
+    double *y = (double *)malloc(sizeof(double) * (size_t)batch * N), *yo = (double *)malloc(sizeof(double) * (size_t)N);
+    unsigned char *u = (unsigned char *)malloc((size_t)batch * N);
+    int *uo = (int *)malloc(sizeof(int) * (size_t)N);
+    gen_state *after = (gen_state *)malloc(sizeof(gen_state) * (size_t)batch);
+    pair_t *pairs = (pair_t *)malloc(sizeof(pair_t) * (size_t)batch * (N / 2));
+    int *mf = (int *)malloc(sizeof(int) * (size_t)batch);
+    pn_init();
+    for (int round = 0; round < 2; round++) {   /* two SNR points: the generator state carries over */
+        const double sigma = po_sigma_from_db(round ? 2.5 : 1.0);
+        make_batch(&g, &c, sigma, batch, u, y, after, pairs, mf);
+        for (int f = 0; f < batch; f++) {
+            po_sim_frame(&s, pc, sigma, uo, yo);
+            int same = 1;
+            for (int j = 0; j < N; j++) same &= (uo[j] == u[(size_t)f * N + j]) && (yo[j] == y[(size_t)f * N + j]);
+            CHECK(same, "polar_sim generator == oracle transmit chain");
+            CHECK(after[f].ranv == s.ranv && after[f].m == s.m, "generator state after the frame");
+            if (!same) break;
+        }
+    }
+    free(y); free(yo); free(u); free(uo); free(after); free(pairs); free(mf);
+    po_code_destroy(pc);
+}
+
+static void oracle_decoders(const int *Q128, const int *Q1024)
+{
+    static const int crc6[] = {0, 5, 6};
+    static const int crc24[] = {0, 1, 2, 4, 8, 12, 13, 15, 17, 20, 21, 23, 24};
+    /* bad arguments are refused, not dereferenced */
+    CHECK(po_code_create(100, 50, 0, NULL, 0, Q128) == NULL, "N not a power of two");
+    CHECK(po_code_create(128, 127, 6, crc6, 3, Q128) == NULL, "K + r > N");
+    int badq[128];
+    for (int i = 0; i < 128; i++) badq[i] = Q128[i];
+    badq[127] = 4096;
+    CHECK(po_code_create(128, 64, 0, NULL, 0, badq) == NULL, "position outside [0, N)");
+    badq[127] = badq[126];
+    CHECK(po_code_create(128, 64, 0, NULL, 0, badq) == NULL, "position listed twice");
+    CHECK(po_code_create_q(128, 64, 0, NULL, 0, Q128, 100) == NULL, "order shorter than N");
+
+    /* published first points: SC_128 (252 frames to 100 errors at 1.0 dB), CASCL_128 seed 8392 (843 to 200) */
+    po_code *sc = po_code_create(128, 64, 0, NULL, 0, Q128);
+    po_code *ca = po_code_create(128, 64, 6, crc6, 3, Q128);
+    po_code *big = po_code_create(1024, 512, 24, crc24, 13, Q1024);
+    const double one = 1.0;
+    long run = 0, eb = 0;
+    CHECK(po_run_sweep(sc, 0, 1, 0, 1024, &one, 1, 100, &run, &eb) == 0 && run == 252, "SC_128 published run count");
+    CHECK(po_run_sweep(ca, 3, 8, 0, 8392, &one, 1, 200, &run, &eb) == 0 && run == 843, "CASCL_128 published run count");
+    /* every decoder once at N = 1024, f64 and f32, L = 1 .. 32; the literal model beside the restatement */
+    po_sim s;
+    po_sim_init(&s, 5);
+    int *u = (int *)malloc(sizeof(int) * 1024), *uh = (int *)malloc(sizeof(int) * 1024), *uh2 = (int *)malloc(sizeof(int) * 1024);
+    double *y = (double *)malloc(sizeof(double) * 1024), *llr = (double *)malloc(sizeof(double) * 1024);
+    float *lf = (float *)malloc(sizeof(float) * 1024);
+    po_lit *lit = po_lit_create(big, 8);
+    for (int f = 0; f < 3; f++) {
+        const double sigma = po_sigma_from_db(1.5);
+        po_sim_frame(&s, big, sigma, u, y);
+        po_llr_from_y(y, sigma, llr, 1024);
+        for (int j = 0; j < 1024; j++) lf[j] = (float)llr[j];
+        double pm, pm2;
+        float pmf;
+        int ties;
+        CHECK(po_sc_decode_f64(big, llr, uh) == 0 && po_sc_decode_f32(big, lf, uh) == 0, "SC");
+        CHECK(po_bp_decode_f64(big, llr, 5, uh) == 0 && po_bp_decode_f32(big, lf, 5, uh) == 0, "BP");
+        for (int L = 1; L <= 32; L *= 2) {
+            CHECK(po_scl_decode_f64(big, llr, L, 1, uh, &pm, &ties) == 0, "CASCL f64");
+            CHECK(po_scl_decode_f32(big, lf, L, 1, uh2, &pmf, &ties) == 0, "CASCL f32");
+            if (L == 8) {
+                CHECK(po_lit_decode(lit, llr, 1, uh2, &pm2) == 0 && pm2 == pm && memcmp(uh, uh2, sizeof(int) * 1024) == 0,
+                      "literal model == restatement");
+            }
+        }
+    }
+    /* a frame full of ties: every metric collides, the literal model must stop where the reference's sort loops */
+    for (int j = 0; j < 1024; j++) llr[j] = (j & 1) ? 8.0 : -8.0;
+    int rc = po_lit_decode(lit, llr, 1, uh2, NULL);
+    CHECK(rc == 0 || rc == -5 || rc == -3, "literal model on an all-ties frame");
+    int ties = 0;
+    CHECK(po_scl_decode_f64(big, llr, 8, 1, uh, NULL, &ties) == 0 && ties > 0, "restatement on an all-ties frame");
+    po_lit_reset(lit);
+    po_lit_poison(lit, 7);
+    po_lit_destroy(lit);
+    free(u); free(uh); free(uh2); free(y); free(llr); free(lf);
+    po_code_destroy(sc); po_code_destroy(ca); po_code_destroy(big);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: %s path/to/q5g_nmax1024.txt\n", argv[0]); return 2; }
+    int *Q128 = load_q(argv[1], 128), *Q1024 = load_q(argv[1], 1024);
+    static const int crc6[] = {0, 5, 6};
+    static const int crc24[] = {0, 1, 2, 4, 8, 12, 13, 15, 17, 20, 21, 23, 24};
+    generator_against_oracle(Q128, 128, 64, 0, NULL, 0, 0, 1024);
+    generator_against_oracle(Q128, 128, 64, 6, crc6, 3, 0, 8392);
+    generator_against_oracle(Q1024, 1024, 512, 24, crc24, 13, 0, 1242);
+    generator_against_oracle(Q1024, 1024, 512, 24, crc24, 13, 1, 4711);
+    oracle_decoders(Q128, Q1024);
+    free(Q128); free(Q1024);
+    if (fails) { fprintf(stderr, "%d check(s) failed\n", fails); return 1; }
+    printf("sanitize_selftest: ok\n");
+    return 0;
+}
