@@ -442,12 +442,12 @@ struct Fast2Dec {
         return c ? m_b : m_a;
     }
 
-    // ---- "every path keeps its better branch" (see decide): true if so for BOTH codewords; bit = that branch ----
-    __device__ __forceinline__ bool trivial_prune(R c0, R c1, uint32_t &bit) const
+    // ---- "every path keeps the branch its lambda favours" (see decide): true if so for BOTH codewords ----
+    // cb / cw = the path's metric with the favoured / the other branch, cb <= cw, valid at pos 0.
+    __device__ __forceinline__ bool trivial_prune(R cb, R cw) const
     {
-        const uint32_t k0 = metric_key(c0), k1 = metric_key(c1);
-        // metrics are valid at pos 0; the other lanes of a path take no part (0 for the max, ~0 for the min)
-        uint32_t mx = min(k0, k1) & pos0_mask, mn = max(k0, k1) | ~pos0_mask;
+        // the other lanes of a path take no part: 0 for the max, ~0 for the min
+        uint32_t mx = metric_key(cb) & pos0_mask, mn = metric_key(cw) | ~pos0_mask;
         mx = max(mx, (uint32_t)dpp_i<0x128>((int)mx));   // row_ror:8: the other path of this row of 16 lanes
         mn = min(mn, (uint32_t)dpp_i<0x128>((int)mn));
         {
@@ -462,10 +462,10 @@ struct Fast2Dec {
             mx = max(a[0], a[1]);
             mn = min(b[0], b[1]);
         }
-        if (__ballot(mx >= mn) != 0ull) return false;
-        bit = (uint32_t)dpp_i<0x00>((int)(k1 < k0 ? 1u : 0u));   // quad_perm [0,0,0,0]: pos 0 decides for its path
-        return true;
+        return __ballot(mx >= mn) == 0ull;
     }
+    static __device__ __forceinline__ uint32_t sign_bit(double x) { return (uint32_t)__double2hiint(x) >> 31; }
+    static __device__ __forceinline__ uint32_t sign_bit(float x) { return (uint32_t)__float_as_int(x) >> 31; }
 
     // ---- decision at leaf j = 8o + K; lambda valid at pos 0 ----
     template <int K>
@@ -477,26 +477,30 @@ struct Fast2Dec {
         if (CRC_ON && !frozen) crcw = crct[j];
         uint32_t bit = 0;
         const R tt = lut.tabv(lam);
-        const R ph0 = tt + negmax(lam);  // PHI(.,0)
         if (frozen) {
-            PM += ph0;
+            PM += tt + negmax(lam);  // PHI(.,0)
         } else {
-            const R ph1 = tt + posmax(lam);  // PHI(.,1)
             if (logact < 3) {
+                const R ph0 = tt + negmax(lam), ph1 = tt + posmax(lam);  // PHI(.,0), PHI(.,1)
                 bit = (p >> logact) & 1;
                 PM += bit ? ph1 : ph0;
                 ++logact;
             } else {
                 POLAR_MARK("d2_phase2");
-                const R c0 = PM + ph0, c1 = PM + ph1;
-                // Most information leaves (85 % at 1-3 dB) prune trivially: every path keeps its better branch.  That
-                // is certain when the largest of the eight smaller keys is below the smallest of the eight larger
-                // keys (the 8 smaller candidates are then the 8 smallest of the 16, all strictly below the median of
-                // SCL_1024.c:619-633), and three max/min steps over the path lanes show it -- without the key
+                // PHI of the branch lambda favours is T(|lambda|), of the other one T(|lambda|) + |lambda|
+                // (SCL_1024.c:481-502; T + 0 is T, so these ARE c0 / c1 in the order the sign of lambda says).
+                const R cb = PM + tt, cw = PM + (tt + absr(lam));
+                const uint32_t lneg = sign_bit(lam);   // lambda = +-0: cb == cw, never trivial, c0 == c1 below
+                // Most information leaves (85 % at 1-3 dB) prune trivially: every path keeps its favoured branch.
+                // That is certain when the largest of the eight favoured keys is below the smallest of the eight
+                // others (the 8 favoured candidates are then the 8 smallest of the 16, all strictly below the median
+                // of SCL_1024.c:619-633), and three max/min steps over the path lanes show it -- without the key
                 // exchange through LDS, the rank network and the fork bookkeeping.  Both codewords must qualify.
-                if (trivial_prune(c0, c1, bit)) {
-                    PM = bit ? c1 : c0;
+                if (trivial_prune(cb, cw)) {
+                    bit = (uint32_t)dpp_i<0x00>((int)lneg);   // quad_perm [0,0,0,0]: pos 0 holds lambda
+                    PM = cb;
                 } else {
+                const R c0 = lneg ? cw : cb, c1 = lneg ? cb : cw;
                 const uint32_t mask = survivors(c0, c1);
                 POLAR_MARK("d2_rank_end");
                 const uint32_t m0 = mask & 0xFFu, m1 = mask >> 8;
