@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "bp_kernel.h"
+#include "bp_r4.h"
 #include "gen_kernel.h"
 #include "probe_kernel.h"
 #include "scl_fast.h"
@@ -355,9 +356,28 @@ bool fast_ok(const polar_ctx *c, int in_is_f32)
     return true;
 }
 
+// N = 1024: the register-blocked kernel (bp_r4.h), two f64 codewords per CU
+template <typename R, typename IN>
+int launch_bp_r4(polar_ctx *c, const polar::BpParams &P)
+{
+    using Cfg = polar::BpR4Cfg<R>;
+    auto kern = polar::k_bp_r4<R, IN>;
+    const size_t lds = Cfg::lds_bytes;
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, Cfg::THREADS, lds));
+    if (occ < 1) occ = 1;
+    int grid = (int)std::min<long long>((long long)P.B, (long long)occ * c->num_cu);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds, c->stream, P);
+    HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
 template <typename R, typename IN>
 int launch_bp(polar_ctx *c, const polar::BpParams &P)
 {
+    if (P.N == 1024 && !c->force_generic) return launch_bp_r4<R, IN>(c, P);
     auto kern = polar::k_bp<R, IN>;
     const size_t lds = polar::bp_lds_bytes<R>(P.N, P.n);
     if (lds > 160 * 1024) {   // messages do not fit a CU's LDS: rows in global scratch
@@ -451,7 +471,7 @@ void refresh_kernel_name(polar_ctx *c)
     const char *ty = g.dtype == POLAR_F32 ? "float" : "double";
     char nm[128];
     if (g.algo == POLAR_ALGO_BP)
-        snprintf(nm, sizeof nm, "k_bp<%s>", ty);
+        snprintf(nm, sizeof nm, (g.N == 1024 && !c->force_generic) ? "k_bp_r4<%s>" : "k_bp<%s>", ty);
     else
         snprintf(nm, sizeof nm, "k_scl_generic<%s,L=%d>", ty, g.L);
     if (g.algo != POLAR_ALGO_BP && g.algo != POLAR_ALGO_SC && !c->force_generic && c->n >= 9 && g.L >= 2)
@@ -1087,7 +1107,7 @@ int polar_testing_big_split(polar_ctx *c, int split)
 
 int polar_testing_math(int op, int is_f32, const void *a, const void *b, void *out, size_t n, int device)
 {
-    if (op < 0 || op > polar::PROBE_PHI_LUT || !a || !b || !out) return POLAR_EINVAL;
+    if (op < 0 || op > polar::PROBE_CHK_IDX || !a || !b || !out) return POLAR_EINVAL;
     if (n == 0) return POLAR_OK;
     DeviceGuard guard(device);
     const size_t es = is_f32 ? 4 : 8;
@@ -1101,10 +1121,10 @@ int polar_testing_math(int op, int is_f32, const void *a, const void *b, void *o
     if (!rc) {
         const int grid = (int)std::min<size_t>((n + 255) / 256, 1024);
         if (is_f32)
-            hipLaunchKernelGGL(polar::k_probe_math<float>, dim3(grid), dim3(256), polar::Lut<float>::bytes, 0, op,
+            hipLaunchKernelGGL(polar::k_probe_math<float>, dim3(grid), dim3(256), polar::Lut<float>::bytes + 16 + 64 * sizeof(float) + polar::Stair<float>::bytes, 0, op,
                                (const float *)da, (const float *)db, (float *)d_out, n);
         else
-            hipLaunchKernelGGL(polar::k_probe_math<double>, dim3(grid), dim3(256), polar::Lut<double>::bytes, 0, op,
+            hipLaunchKernelGGL(polar::k_probe_math<double>, dim3(grid), dim3(256), polar::Lut<double>::bytes + 16 + 64 * sizeof(double) + polar::Stair<double>::bytes, 0, op,
                                (const double *)da, (const double *)db, (double *)d_out, n);
         if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
             hipMemcpy(out, d_out, n * es, hipMemcpyDeviceToHost) != hipSuccess)

@@ -188,4 +188,109 @@ __device__ __forceinline__ R chk_lut(R a, R b, const Lut<R> &L)
 }
 
 
+// ---- the staircase on the VALU (for BP, where the table reads of the forms above saturate the LDS pipe) ----------
+// n(x) = #{k : |x| < thr_k}, 0..7, exact: |x| - thr_k is negative exactly when |x| < thr_k (an IEEE difference has the
+// sign of the exact difference, and +0 when they are equal), and v_alignbit shifts that sign bit into an accumulator:
+// one subtraction and one full-rate instruction per threshold, no compare, no select, no memory.  T(|x|) is then
+// tv[7 - n] (SCL_1024.c:352-359), and T(|s|) - T(|d|) one read of an 8x8 table of the IEEE differences.
+__device__ __forceinline__ uint32_t hi_word(double x) { return (uint32_t)__double2hiint(x); }
+__device__ __forceinline__ uint32_t hi_word(float x) { return (uint32_t)__float_as_int(x); }
+
+template <typename R>
+__device__ __forceinline__ uint32_t below_count(R x)
+{
+    const R a = absr(x);
+    uint32_t acc = 0;
+    acc = __builtin_amdgcn_alignbit(acc, hi_word(a - R(0.196)), 31);
+    acc = __builtin_amdgcn_alignbit(acc, hi_word(a - R(0.433)), 31);
+    acc = __builtin_amdgcn_alignbit(acc, hi_word(a - R(0.71)), 31);
+    acc = __builtin_amdgcn_alignbit(acc, hi_word(a - R(1.05)), 31);
+    acc = __builtin_amdgcn_alignbit(acc, hi_word(a - R(1.508)), 31);
+    acc = __builtin_amdgcn_alignbit(acc, hi_word(a - R(2.252)), 31);
+    acc = __builtin_amdgcn_alignbit(acc, hi_word(a - R(4.5)), 31);
+    return (uint32_t)__popc(acc);
+}
+
+// dn[ns * 8 + nd] = T(level 7 - ns) - T(level 7 - nd): built once per workgroup into LDS (512 B in f64)
+template <typename R>
+__device__ void build_delta_by_count(R *dn, int tid, int nthreads)
+{
+    const R tv[8] = {R(0.65), R(0.55), R(0.45), R(0.35), R(0.25), R(0.15), R(0.05), R(0)};
+    for (int i = tid; i < 64; i += nthreads) dn[i] = tv[7 - (i >> 3)] - tv[7 - (i & 7)];
+}
+
+// CHK (SCL_1024.c:343-374) with the staircase counted on the VALU; same value as chk / chk_lut / chk_lut1
+template <typename R>
+__device__ __forceinline__ R chk_cnt(R a, R b, const R *dn)
+{
+    const uint32_t ns = below_count<R>(a + b), nd = below_count<R>(a - b);
+    const R delta = dn[ns * 8 + nd];
+    return xor_sign(minabs(a, b), a, b) + delta;
+}
+
+// ---- the staircase with ONE small table read (for BP) -----------------------------------------------------------
+// Four cells per binade over [0.125, 8) (26 cells with the two ends) still separate the seven thresholds, so the number
+// b of thresholds in the cells below x's own is a prefix popcount of a 26-bit mask -- three full-rate instructions --
+// and the only threshold that can still lie at or below |x| is thr[b] (the next one up; +inf after the last): the
+// level index is b + (|x| >= thr[b]).  The read of thr[b] touches eight addresses in sixteen different LDS banks: no
+// conflicts, 8 bytes per look-up instead of 16 from 50 scattered cells; T(|s|) - T(|d|) is one more 8-byte read.
+template <typename R>
+struct Cell4;
+template <>
+struct Cell4<double> {
+    static constexpr int BIAS = 0x3FC00000 >> 18;   // cell number of 0.125
+    static __device__ __forceinline__ int raw(double x) { return (int)__builtin_amdgcn_ubfe((unsigned)__double2hiint(x), 18, 13); }
+};
+template <>
+struct Cell4<float> {
+    static constexpr int BIAS = 0x3E000000 >> 21;
+    static __device__ __forceinline__ int raw(float x) { return (int)__builtin_amdgcn_ubfe((unsigned)__float_as_int(x), 21, 10); }
+};
+
+template <typename R>
+struct Stair {
+    static constexpr size_t bytes = sizeof(R) * (8 + 64);
+    const R *thr;    // LDS [8]: the seven thresholds, then +inf
+    const R *dlt;    // LDS [64]: dlt[i * 8 + j] = T_i - T_j
+    uint32_t mask;   // bit c set: cell c holds a threshold
+
+    static __device__ __forceinline__ int cell_of(R x)
+    {
+        const int t = Cell4<R>::raw(x);
+        return min(max(t, Cell4<R>::BIAS - 1), Cell4<R>::BIAS + 24) - (Cell4<R>::BIAS - 1);
+    }
+    static __device__ void build(unsigned char *mem, int tid, int nthreads)
+    {
+        R *t = reinterpret_cast<R *>(mem);
+        const R thr7[8] = {R(0.196), R(0.433), R(0.71), R(1.05), R(1.508), R(2.252), R(4.5), R(__builtin_huge_val())};
+        const R tv[8] = {R(0.65), R(0.55), R(0.45), R(0.35), R(0.25), R(0.15), R(0.05), R(0)};
+        for (int i = tid; i < 8; i += nthreads) t[i] = thr7[i];
+        for (int i = tid; i < 64; i += nthreads) t[8 + i] = tv[i >> 3] - tv[i & 7];
+    }
+    __device__ __forceinline__ void bind(const unsigned char *mem)
+    {
+        thr = reinterpret_cast<const R *>(mem);
+        dlt = thr + 8;
+        const R thr7[7] = {R(0.196), R(0.433), R(0.71), R(1.05), R(1.508), R(2.252), R(4.5)};
+        mask = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) mask |= 1u << cell_of(thr7[k]);
+    }
+    // level index of |x|: #{k : thr_k <= |x|}
+    __device__ __forceinline__ uint32_t level(R x) const
+    {
+        const uint32_t c = (uint32_t)cell_of(x);
+        const uint32_t b = (uint32_t)__popc(mask & ((1u << c) - 1u));
+        return b + ((absr(x) >= thr[b]) ? 1u : 0u);
+    }
+};
+
+template <typename R>
+__device__ __forceinline__ R chk_idx(R a, R b, const Stair<R> &S)
+{
+    const uint32_t is = S.level(a + b), id = S.level(a - b);
+    const R delta = S.dlt[is * 8 + id];
+    return xor_sign(minabs(a, b), a, b) + delta;
+}
+
 }  // namespace polar

@@ -7,7 +7,7 @@
 
 namespace polar {
 
-enum { PROBE_CHK = 0, PROBE_CHK_LUT = 1, PROBE_CHK_LUT1 = 2, PROBE_TABV = 3, PROBE_PHI = 4, PROBE_PHI_LUT = 5 };
+enum { PROBE_CHK = 0, PROBE_CHK_LUT = 1, PROBE_CHK_LUT1 = 2, PROBE_TABV = 3, PROBE_PHI = 4, PROBE_PHI_LUT = 5, PROBE_CHK_CNT = 6, PROBE_CHK_IDX = 7 };
 
 // the metric increment exactly as the list kernels write it (scl_fast2.h decide, scl_big.h, scl_generic.h)
 template <typename R>
@@ -22,6 +22,12 @@ __global__ void __launch_bounds__(256) k_probe_math(int op, const R *a, const R 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Lut<R>::build(smem, (int)threadIdx.x, (int)blockDim.x);
+    R *dn = reinterpret_cast<R *>(smem + ((Lut<R>::bytes + 15) / 16) * 16);
+    build_delta_by_count<R>(dn, (int)threadIdx.x, (int)blockDim.x);
+    unsigned char *stm = reinterpret_cast<unsigned char *>(dn + 64);
+    Stair<R>::build(stm, (int)threadIdx.x, (int)blockDim.x);
+    Stair<R> st;
+    st.bind(stm);
     __syncthreads();
     Lut<R> lut;
     lut.bind(smem);
@@ -34,6 +40,8 @@ __global__ void __launch_bounds__(256) k_probe_math(int op, const R *a, const R 
         case PROBE_CHK_LUT1: r = chk_lut1<R>(x, y, lut); break;
         case PROBE_TABV: r = lut.tabv(x); break;
         case PROBE_PHI: r = phi<R>(x, y != R(0) ? 1 : 0); break;
+        case PROBE_CHK_CNT: r = chk_cnt<R>(x, y, dn); break;
+        case PROBE_CHK_IDX: r = chk_idx<R>(x, y, st); break;
         default: r = phi_lut<R>(x, y != R(0) ? 1 : 0, lut); break;
         }
         out[i] = r;

@@ -9,6 +9,7 @@ import polardecoding_amd as pa
 ap = argparse.ArgumentParser()
 ap.add_argument("--only", default="")
 ap.add_argument("--dtype", default="f64")
+ap.add_argument("--variant", type=int, default=0, help="polar_hip_testing.h kernel variant (0 = the library's choice)")
 args = ap.parse_args()
 dt = pa.F64 if args.dtype == "f64" else pa.F32
 tdt = torch.float64 if args.dtype == "f64" else torch.float32
@@ -20,7 +21,7 @@ def llrs(B, N):
 
 CONFIGS = [
     ("SC_1024", lambda: pa.SCdecode(1024, 512, dtype=dt), 1024, 1 << 18),
-    ("BP_1024_50it", lambda: pa.BP(1024, 512, iterMax=50, dtype=dt), 1024, 1 << 13),
+    ("BP_1024_50it", lambda: pa.BP(1024, 512, iterMax=50, dtype=dt), 1024, 1 << 16),
     ("SCL_1024_L8", lambda: pa.SCLdecode(1024, 512, L=8, dtype=dt), 1024, 1 << 16),
     ("CASCL_1024_L8", lambda: pa.CASCL(1024, 512, L=8, dtype=dt), 1024, 1 << 17),
     ("CASCL_128_L8", lambda: pa.CASCL(128, 64, L=8, crc_taps=pa.CRC6_TAPS, dtype=dt), 128, 1 << 18),
@@ -31,6 +32,9 @@ for name, mk, N, B in CONFIGS:
     if args.only and args.only not in name:
         continue
     dec = mk()
+    if args.variant:
+        from polardecoding_amd import testing as T
+        T.select_kernel(dec, args.variant)
     x = llrs(B, N)
     out = torch.empty(B, N // 32, dtype=torch.int32, device="cuda")
     dec.decode_device(x, out_bits=out); dec.synchronize()
