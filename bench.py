@@ -35,7 +35,7 @@ N, K = 1024, 512
 CRC = (0, 1, 2, 4, 8, 12, 13, 15, 17, 20, 21, 23, 24)   # CRC-24C, CASCL_1024_L8.c:2-4 (= polardecoding_amd.CRC24C_TAPS)
 R = max(CRC)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-TRAFFIC_PROFILE = "r01_traffic.json"   # latest committed rocprofv3 --pmc summary of the headline kernel
+TRAFFIC_PROFILE = "r02_traffic.json"   # latest committed rocprofv3 --pmc summary of the headline kernel
 
 
 def host_cpu_model():

@@ -10,6 +10,24 @@ for f in glob.glob(f"{d}/stats/*/*_kernel_stats.csv"):
     print("Name,Calls,TotalDurationNs,AverageNs,Percentage")
     for r in rows[:4]:
         print(",".join([r["Name"][:70], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]]))
+# per-dispatch view of the decode kernels: bench.py alternates its steps over two streams, so consecutive dispatches
+# time-share the CUs and the trace stretches them; the dispatches that ran alone are the kernel's own duration
+for f in glob.glob(f"{d}/stats/*/*_kernel_trace.csv"):
+    rows = [r for r in csv.DictReader(open(f)) if "polar::k_" in r["Kernel_Name"] and "k_count" not in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    if rows:
+        print("## kernel-trace, per dispatch (ms from the first; 'alone' = overlaps no other decode dispatch)")
+        t0 = int(rows[0]["Start_Timestamp"])
+        alone = collections.defaultdict(list)
+        for i, r in enumerate(rows):
+            a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            ov = any(j != i and int(q["Start_Timestamp"]) < b and int(q["End_Timestamp"]) > a for j, q in enumerate(rows))
+            kn = r["Kernel_Name"].split("(")[0].replace("void polar::", "")
+            print(f"{kn:42s} start {(a - t0) / 1e6:9.3f}  duration {(b - a) / 1e6:8.3f} ms  {'overlapped' if ov else 'alone'}")
+            if not ov:
+                alone[kn].append((b - a) / 1e6)
+        for kn, v in alone.items():
+            print(f"{kn:42s} average of the {len(v)} dispatches that ran alone: {sum(v) / len(v):.3f} ms")
 print("## PMC (sum over the chip, per dispatch of the decode kernel, and per frame)")
 for sub in sorted(glob.glob(f"{d}/pmc*")):
     for f in glob.glob(f"{sub}/*/*_counter_collection.csv"):
