@@ -540,6 +540,28 @@ struct FastDec {
         return mask;
     }
 
+    // true if every path keeps the branch its lambda favours (cb <= cw: its metric with that / the other branch, at pos 0)
+    __device__ __forceinline__ bool trivial_prune(R cb, R cw) const
+    {
+        const uint32_t m0 = pos == 0 ? 0xFFFFFFFFu : 0u;
+        uint32_t mx = metric_key(cb) & m0, mn = metric_key(cw) | ~m0;
+        mx = max(mx, (uint32_t)dpp_i<0x128>((int)mx));   // row_ror:8: the other path of this row of 16 lanes
+        mn = min(mn, (uint32_t)dpp_i<0x128>((int)mn));
+        {
+            auto a = __builtin_amdgcn_permlane16_swap(mx, mx, false, false);
+            auto b = __builtin_amdgcn_permlane16_swap(mn, mn, false, false);
+            mx = max(a[0], a[1]);
+            mn = min(b[0], b[1]);
+        }
+        {
+            auto a = __builtin_amdgcn_permlane32_swap(mx, mx, false, false);
+            auto b = __builtin_amdgcn_permlane32_swap(mn, mn, false, false);
+            mx = max(a[0], a[1]);
+            mn = min(b[0], b[1]);
+        }
+        return __ballot(mx >= mn) == 0ull;
+    }
+
     // ---- decision at leaf j = 8o + K given lambda (valid at pos 0) ----
     template <int K>
     __device__ __forceinline__ void decide(int o, bool frozen, R lam)
@@ -550,22 +572,32 @@ struct FastDec {
         if (CRC_ON && !frozen) crcw = crct[j];
         uint32_t bit = 0;
         const R tt = lut.tabv(lam);
-        // PHI(.,0) = T + (lam < 0 ? |lam| : 0)  (SCL_1024.c:481-502); T + 0 is exact
-        const R ph0 = tt + negmax(lam);
         if (frozen) {
-            PM += ph0;  // SCL_1024.c:601-604, :662-665
+            // PHI(.,0) = T + (lam < 0 ? |lam| : 0)  (SCL_1024.c:481-502); T + 0 is exact
+            PM += tt + negmax(lam);  // SCL_1024.c:601-604, :662-665
         } else {
-            const R ph1 = tt + posmax(lam);  // PHI(.,1) = T + (lam > 0 ? |lam| : 0)
             if (logact < 3) {
                 // phase 1 (SCL_1024.c:586-600): group q is slot q mod 2^logact; the fork sends the replicas
                 // with bit `logact` of q set down the 1-branch
+                const R ph0 = tt + negmax(lam), ph1 = tt + posmax(lam);  // PHI(.,1) = T + (lam > 0 ? |lam| : 0)
                 bit = (p >> logact) & 1;
                 PM += bit ? ph1 : ph0;
                 ++logact;
             } else {
                 // phase 2 (SCL_1024.c:610-661)
                 POLAR_MARK("phase2_begin");
-                const R c0 = PM + ph0, c1 = PM + ph1;
+                // the branch lambda favours costs T(|lambda|), the other one T(|lambda|) + |lambda|: these ARE c0 / c1 in
+                // the order the sign of lambda says.  If the largest favoured key is below the smallest other key, the
+                // eight favoured candidates are the eight smallest of the sixteen (85 % of the information leaves at
+                // 1-3 dB): every path keeps its favoured branch, no ranking, no fork (scl_fast2.h has the long version)
+                const R cb = PM + tt, cw = PM + (tt + absr(lam));
+                const uint32_t lneg = hi_word(lam) >> 31;
+                // (measured: +4 % at N = 1024, -1 ... -5 % at N = 128, where the short frames are not bound by this step)
+                if (BIG && trivial_prune(cb, cw)) {
+                    bit = (uint32_t)__shfl((int)lneg, p * 8);   // pos 0 holds lambda
+                    PM = cb;
+                } else {
+                const R c0 = lneg ? cw : cb, c1 = lneg ? cb : cw;
                 const uint32_t mask = survivors(c0, c1);
                 POLAR_MARK("rank_end");
                 const uint32_t m0 = mask & 0xFFu, m1 = mask >> 8;
@@ -607,6 +639,7 @@ struct FastDec {
                     else if (s0) { bit = 0; PM = c0; }
                     else if (s1) { bit = 1; PM = c1; }
                     else { bit = 0; PM = c0; }  // tie rule: un-refilled dead slot continues as its 0-branch
+                }
                 }
             }
             POLAR_MARK("fork_end");
