@@ -22,6 +22,7 @@ extern "C" {
 #define POLAR_TEST_KERNEL_GENERIC_SPILL 2  /* k_scl_generic, every LLR level in global scratch                       */
 #define POLAR_TEST_KERNEL_BIG 3            /* k_scl_big (N >= 512, L >= 2) also where a tuned L = 8 kernel exists    */
 #define POLAR_TEST_KERNEL_ONE_PER_WAVE 4   /* N = 1024, L = 8: k_scl_fast (one codeword per wavefront), not the pair */
+#define POLAR_TEST_KERNEL_FOUR_PER_WAVE 5  /* N = 1024, L = 8: k_scl_fast4 (four codewords per wavefront)            */
 int polar_testing_select_kernel(polar_ctx *ctx, int variant);
 
 /* k_scl_big: LLR levels <= TL and partial-sum levels <= TB in LDS, written as the two digits TL TB:

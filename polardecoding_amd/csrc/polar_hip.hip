@@ -21,6 +21,7 @@
 #include "probe_kernel.h"
 #include "scl_fast.h"
 #include "scl_fast2.h"
+#include "scl_fast4.h"
 #include "scl_generic.h"
 #include "scl_big.h"
 #include "sc_lanes.h"
@@ -70,6 +71,7 @@ struct polar_ctx {
     // kernel selection overrides, set only through include/polar_hip_testing.h (cross-checks of the tuned kernels)
     bool force_generic = false;
     bool use_fast2 = true;      // false: one codeword per wavefront (k_scl_fast) instead of two at N = 1024
+    bool use_fast4 = false;     // four codewords per wavefront (k_scl_fast4) at N = 1024
     bool force_spill = false;   // no tuned L = 8 kernel; with force_generic: the global-scratch variant of k_scl_generic
     int big_split = 0;          // 35 | 46 | 57: LDS / scratch split of k_scl_big; 0 = the measured best
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -337,9 +339,37 @@ int launch_fast2(polar_ctx *c, const polar::SclParams &P)
     return POLAR_OK;
 }
 
+// four codewords per wavefront (scl_fast4.h), N = 1024, L = 8
+template <typename R, typename IN, bool CRC_ON>
+int launch_fast4(polar_ctx *c, const polar::SclParams &P)
+{
+    using Cfg = polar::Fast4Cfg<R>;
+    auto kern = polar::k_scl_fast4<R, IN, CRC_ON>;
+    constexpr int WAVES = Cfg::WAVES;
+    const size_t lds = Cfg::total;
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WAVES, lds));
+    if (occ < 1) occ = 1;
+    const long long quads = ((long long)P.B + Cfg::CW - 1) / Cfg::CW;
+    long long blocks_needed = (quads + WAVES - 1) / WAVES;
+    int grid = (int)std::min<long long>(blocks_needed, (long long)occ * c->num_cu);
+    if (grid < 1) grid = 1;
+    polar::SclParams Q = P;
+    const size_t sc_bytes = Cfg::scratch_elems * sizeof(R) * (size_t)grid * WAVES;
+    int rc = ensure(c, c->scratch, sc_bytes);
+    if (rc) return rc;
+    Q.scratch = c->scratch.p;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, c->stream, Q);
+    HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
 template <typename R, typename IN>
 int launch_fast_n(polar_ctx *c, const polar::SclParams &P, bool crc)
 {
+    if (P.N == 1024 && c->use_fast4) return crc ? launch_fast4<R, IN, true>(c, P) : launch_fast4<R, IN, false>(c, P);
     if (P.N == 1024 && c->use_fast2) return crc ? launch_fast2<R, IN, true>(c, P) : launch_fast2<R, IN, false>(c, P);
     if (P.N == 1024) return crc ? launch_fast<R, IN, 10, true>(c, P) : launch_fast<R, IN, 10, false>(c, P);
     if (P.N == 128) return crc ? launch_fast<R, IN, 7, true>(c, P) : launch_fast<R, IN, 7, false>(c, P);
@@ -479,7 +509,7 @@ void refresh_kernel_name(polar_ctx *c)
     if (g.algo == POLAR_ALGO_SC && !c->force_generic && g.N <= 2048)
         snprintf(nm, sizeof nm, "k_sc_lanes<%s> (batches of 64+; k_scl_generic below)", ty);
     if (fast_ok(c, g.dtype == POLAR_F32))
-        snprintf(nm, sizeof nm, "k_scl_fast%s<%s,N=%d,L=8>", (g.N == 1024 && c->use_fast2) ? "2" : "", ty, g.N);
+        snprintf(nm, sizeof nm, "k_scl_fast%s<%s,N=%d,L=8>", (g.N == 1024 && c->use_fast4) ? "4" : (g.N == 1024 && c->use_fast2) ? "2" : "", ty, g.N);
     c->kernel_name = nm;
 }
 
@@ -1090,10 +1120,11 @@ int polar_fer_batch(polar_ctx *c, unsigned long long seed, unsigned long long fi
 // ---- include/polar_hip_testing.h ----------------------------------------------------------------------------
 int polar_testing_select_kernel(polar_ctx *c, int variant)
 {
-    if (!c || variant < POLAR_TEST_KERNEL_AUTO || variant > POLAR_TEST_KERNEL_ONE_PER_WAVE) return POLAR_EINVAL;
+    if (!c || variant < POLAR_TEST_KERNEL_AUTO || variant > POLAR_TEST_KERNEL_FOUR_PER_WAVE) return POLAR_EINVAL;
     c->force_generic = (variant == POLAR_TEST_KERNEL_GENERIC || variant == POLAR_TEST_KERNEL_GENERIC_SPILL);
     c->force_spill = (variant == POLAR_TEST_KERNEL_GENERIC_SPILL || variant == POLAR_TEST_KERNEL_BIG);
     c->use_fast2 = (variant != POLAR_TEST_KERNEL_ONE_PER_WAVE);
+    c->use_fast4 = (variant == POLAR_TEST_KERNEL_FOUR_PER_WAVE);
     refresh_kernel_name(c);
     return POLAR_OK;
 }

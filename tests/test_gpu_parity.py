@@ -297,3 +297,30 @@ def test_bp_readouts_vs_oracle_n512(oracle):
     # what the plain BP kernel decides after the same number of iterations
     uh, _, _ = dec.decode_batch(llr)
     assert np.array_equal(uh, ref_uh)
+
+
+@pytest.mark.parametrize("variant", ["FOUR_PER_WAVE", "AUTO", "ONE_PER_WAVE"])
+@pytest.mark.parametrize("algo,dtype,B", [("CASCL", "f64", 203), ("SCL", "f64", 64), ("CASCL", "f32", 130), ("CASCL", "f64", 1)])
+def test_tuned_list_kernels_vs_oracle(variant, algo, dtype, B, oracle):
+    """The three tuned L = 8 kernels for N = 1024 (one, two, four codewords per wavefront) on the same seeded frames:
+    decisions, path metric and flags of the oracle; batch sizes that leave the last wavefront partly filled."""
+    import polardecoding_amd as pa
+    from polardecoding_amd import testing as T
+    N, K = 1024, 512
+    taps = pa.CRC24C_TAPS if algo == "CASCL" else None
+    code = oracle.Code(N, K, taps)
+    dt = pa.F64 if dtype == "f64" else pa.F32
+    dec = pa.CASCL(N, K, L=8, dtype=dt) if algo == "CASCL" else pa.SCLdecode(N, K, L=8, dtype=dt)
+    T.select_kernel(dec, getattr(T, "KERNEL_" + variant))
+    sim = oracle.Sim(900 + B)
+    llrs = []
+    for db in (0.5, 1.5, 2.5):
+        sig = oracle.sigma_from_db(db)
+        _, ys = sim.frames(code, sig, (B + 2) // 3)
+        llrs.append(np.stack([oracle.llr_from_y(y, sig) for y in ys]))
+    llr = np.concatenate(llrs)[:B].astype(np.float32).astype(np.float64)
+    ref_uh, ref_pm, ref_t = oracle.decode(code, llr, algo, L=8, dtype=dtype)
+    uh, pm, fl = dec.decode_batch(llr)
+    assert np.array_equal(uh, ref_uh)
+    assert np.array_equal(pm.astype(np.float32 if dtype == "f32" else np.float64), ref_pm)
+    assert np.array_equal((fl & pa.FLAG_TIE) != 0, ref_t > 0)

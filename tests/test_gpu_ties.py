@@ -24,7 +24,8 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def _variants(N):
     from polardecoding_amd import testing as T
     if N == 1024:
-        return [("auto", T.KERNEL_AUTO, "k_scl_fast2"), ("one_per_wave", T.KERNEL_ONE_PER_WAVE, "k_scl_fast<"),
+        return [("auto", T.KERNEL_AUTO, "k_scl_fast"), ("two_per_wave", T.KERNEL_AUTO, "k_scl_fast"),
+                ("four_per_wave", T.KERNEL_FOUR_PER_WAVE, "k_scl_fast4"), ("one_per_wave", T.KERNEL_ONE_PER_WAVE, "k_scl_fast<"),
                 ("big", T.KERNEL_BIG, "k_scl_big"), ("generic", T.KERNEL_GENERIC, "k_scl_generic"),
                 ("generic_spill", T.KERNEL_GENERIC_SPILL, "k_scl_generic")]
     return [("auto", T.KERNEL_AUTO, "k_scl_fast<"), ("generic", T.KERNEL_GENERIC, "k_scl_generic"),
@@ -75,7 +76,7 @@ def _oracle_f32_parallel(oracle, code, llr32, algo, L, workers=12):
     return (np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res]), np.concatenate([r[2] for r in res]))
 
 
-@pytest.mark.parametrize("variant", ["auto", "one_per_wave", "big"])
+@pytest.mark.parametrize("variant", ["auto", "four_per_wave", "one_per_wave", "big"])
 def test_f32_batch_with_natural_ties_matches_f32_oracle(variant, oracle):
     """float metrics collide by themselves (0.1-0.25 % of frames at 1 dB): 24 576 frames of CA-SCL
     N = 1024 L = 8 at 1.0 dB, bit-identical to the f32 oracle: decisions, metric, and the tie flag."""
