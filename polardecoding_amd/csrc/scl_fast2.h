@@ -791,8 +791,24 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
         }
         for (int o = o_first; o < N / 8; ++o) {
             if ((o & 3) == 0) fword = frz[o >> 2];
+#ifdef POLAR_STAMPS_HEADS   // finer split of the octet heads: 0 from_top, 1 from_l8, 7 from_l7, 3 register g steps, 2 f chains
+            {
+                const int d = (o == 0) ? 10 : 3 + __builtin_ctz((unsigned)o);
+                if (d >= 8) { s.from_top(o >= N / 16, d == 8); STAMP(0); }
+                else if (d == 7) { s.from_l8(); STAMP(1); }
+                else if (d == 6) { s.from_l7(); STAMP(7); }
+                else if (d == 5) { s.template g_reg<5>(); STAMP(3); }
+                else if (d == 4) { s.template g_reg<4>(); STAMP(3); }
+                else { s.g3(); STAMP(3); }
+                if (d > 5) s.template f_reg<5>();
+                if (d > 4) s.template f_reg<4>();
+                if (d > 3) s.template f_reg<3>();
+                STAMP(2);
+            }
+#else
             s.octet_head(o);
             if (o == 0 || (o & 7) == 0) STAMP(7); else STAMP(3);
+#endif
             const uint32_t fm = (fword >> (8 * (o & 3))) & 0xFFu;
             if ((fm & 0x7Fu) == 0x7Fu) { s.octet_frozen_prefix(o, fm == 0xFFu); STAMP(4); }
             else { s.octet(o, fm); STAMP(5); }

@@ -56,11 +56,20 @@ for dtype in ("f64", "f32"):
             code = O.Code(N, K, None, Q=q_of(dec, N, K, None))
             for B in (int(rng.integers(1, 63)), int(rng.integers(64, 200))):
                 check(f"SC N={N} K={K} {dtype}", dec, code, "SC", 1, B, 2.0 if K * 2 <= N else 5.0, dtype)
-    # BP
-    for N, it in ((32, 7), (128, 20), (512, 11), (1024, 6), (2048, 4), (4096, 3)):   # above 1024: rows in global scratch
-        K = N // 2
+    # the four tuned L = 8 kernels for N = 1024 side by side (one, two, four codewords per wavefront; big-list kernel)
+    from polardecoding_amd import testing as T
+    for variant in ("AUTO", "ONE_PER_WAVE", "FOUR_PER_WAVE", "BIG"):
+        for K, taps in ((512, pa.CRC24C_TAPS), (256, None), (768, pa.CRC6_TAPS), (1000, None), (24, None)):
+            dec = pa.CASCL(1024, K, L=8, crc_taps=taps, dtype=dt) if taps else pa.SCLdecode(1024, K, L=8, dtype=dt)
+            T.select_kernel(dec, getattr(T, "KERNEL_" + variant))
+            code = O.Code(1024, K, taps, Q=q_of(dec, 1024, K, taps))
+            check(f"{variant} N=1024 K={K} r={max(taps) if taps else 0} {dtype}", dec, code, "CASCL" if taps else "SCL", 8,
+                  int(rng.integers(1, 40)), 1.5 if K <= 512 else 4.5, dtype)
+    # BP (N = 1024: the register-blocked kernel, several rates and iteration counts)
+    for N, K, it in ((32, 16, 7), (128, 64, 20), (512, 256, 11), (1024, 512, 6), (1024, 200, 13), (1024, 900, 50), (2048, 1024, 4),
+                     (4096, 2048, 3)):   # above 1024: rows in global scratch
         dec = pa.BP(N, K, iterMax=it, dtype=dt)
         code = O.Code(N, K, None, Q=q_of(dec, N, K, None))
-        check(f"BP N={N} K={K} it={it} {dtype}", dec, code, "BP", 1, int(rng.integers(3, 12)), 2.0, dtype, iters=it)
+        check(f"BP N={N} K={K} it={it} {dtype}", dec, code, "BP", 1, int(rng.integers(3, 12)), 2.0 if K * 2 <= N else 5.0, dtype, iters=it)
 print(f"{bad} mismatching configurations, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
