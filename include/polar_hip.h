@@ -169,6 +169,16 @@ int polar_generate_device(polar_ctx *ctx, unsigned long long seed, unsigned long
 int polar_fer_batch(polar_ctx *ctx, unsigned long long seed, unsigned long long first_frame, double snr_db, size_t B,
                     unsigned long long *block_errors, unsigned long long *bit_errors);
 
+/* The same over the GPUs of one node (frames are independent, so the range first_frame .. first_frame +
+ * ngpus * frames_per_gpu is cut into contiguous shards, one per GPU, each decoded by its own context on its own host thread;
+ * no data-path collective).  The only exchange is the sum of the two counters, one ncclAllReduce of 2 x uint64 over RCCL /
+ * xGMI, which is loaded with dlopen() on first use (POLAR_EDEVICE if the machine has none or fewer than ngpus devices).
+ * Frame f of the range is the same frame whatever ngpus is (counter-based generator): the totals equal polar_fer_batch over
+ * the whole range on one GPU.  seconds (nullable): the slowest GPU's time for its shard. */
+int polar_fer_multi_gpu(const polar_cfg *cfg, int ngpus, unsigned long long seed, unsigned long long first_frame,
+                        double snr_db, size_t frames_per_gpu, unsigned long long *block_errors,
+                        unsigned long long *bit_errors, double *seconds);
+
 /* stream plumbing: the ctx owns a stream by default; a host framework may hand in its own
  * (hipStream_t passed as void*). */
 int polar_set_stream(polar_ctx *ctx, void *hip_stream);

@@ -77,6 +77,8 @@ def load_library():
                                         C.c_int, vp]
     L.polar_fer_batch.argtypes = [vp, C.c_ulonglong, C.c_ulonglong, C.c_double, C.c_size_t, C.POINTER(C.c_ulonglong),
                                   C.POINTER(C.c_ulonglong)]
+    L.polar_fer_multi_gpu.argtypes = [C.POINTER(_Cfg), C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_double, C.c_size_t,
+                                      C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_double)]
     L.polar_set_stream.argtypes = [vp, vp]
     L.polar_get_stream.restype = vp
     L.polar_get_stream.argtypes = [vp]
@@ -127,6 +129,7 @@ class Decoder:
         if info_order is not None:
             io = np.ascontiguousarray(info_order, dtype=np.int32)
             cfg.info_order = _ptr(io, C.c_int)
+        self._cfg, self._cfg_keep = cfg, (taps, io)   # kept for polar_fer_multi_gpu (the arrays the struct points to must stay alive)
         rc = self._lib.polar_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()
@@ -242,6 +245,15 @@ class Decoder:
         self._check(self._lib.polar_fer_batch(self._h, int(seed), int(first_frame), float(snr_db), int(B),
                                               C.byref(blk), C.byref(bits)), "polar_fer_batch")
         return blk.value, bits.value
+
+    def fer_multi_gpu(self, ngpus, seed, first_frame, snr_db, frames_per_gpu):
+        """polar_fer_batch over the GPUs of this node (one shard of frames_per_gpu frames each, own context and host thread
+        per GPU, RCCL all-reduce of the two counters): returns (block_errors, bit_errors, seconds of the slowest GPU)."""
+        blk, bits, sec = C.c_ulonglong(0), C.c_ulonglong(0), C.c_double(0)
+        self._check(self._lib.polar_fer_multi_gpu(C.byref(self._cfg), int(ngpus), int(seed), int(first_frame), float(snr_db),
+                                                  int(frames_per_gpu), C.byref(blk), C.byref(bits), C.byref(sec)),
+                    "polar_fer_multi_gpu")
+        return blk.value, bits.value, sec.value
 
     def count_errors_device(self, uhat_bits, u_bits, counters, frame_err=None):
         B = uhat_bits.shape[0]

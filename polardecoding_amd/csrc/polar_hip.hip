@@ -5,7 +5,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1062,12 +1065,10 @@ int polar_generate_device(polar_ctx *c, unsigned long long seed, unsigned long l
     return POLAR_OK;
 }
 
-int polar_fer_batch(polar_ctx *c, unsigned long long seed, unsigned long long first_frame, double snr_db, size_t B,
-                    unsigned long long *block_errors, unsigned long long *bit_errors)
+// generate -> decode -> count for B frames; the two counters stay in c->gen_cnt (device) and are copied to h[2] if h != null
+static int fer_batch_impl(polar_ctx *c, unsigned long long seed, unsigned long long first_frame, double snr_db, size_t B,
+                          unsigned long long *h)
 {
-    if (!c || !block_errors || !bit_errors) return POLAR_EINVAL;
-    DeviceGuard guard(c->cfg.device);
-    if (B == 0) return POLAR_OK;
     const int N = c->cfg.N, NW = c->NW;
     const bool f32 = c->cfg.dtype == POLAR_F32;
     int rc;
@@ -1109,13 +1110,141 @@ int polar_fer_batch(polar_ctx *c, unsigned long long seed, unsigned long long fi
     }
     if ((rc = run_part(0, half))) return rc;
     if (half < B) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_b, 0));
-    unsigned long long h[2];
-    HIP_TRY(c, hipMemcpyAsync(h, c->gen_cnt.p, 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h) {
+        HIP_TRY(c, hipMemcpyAsync(h, c->gen_cnt.p, 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return POLAR_OK;
+}
+
+int polar_fer_batch(polar_ctx *c, unsigned long long seed, unsigned long long first_frame, double snr_db, size_t B,
+                    unsigned long long *block_errors, unsigned long long *bit_errors)
+{
+    if (!c || !block_errors || !bit_errors) return POLAR_EINVAL;
+    DeviceGuard guard(c->cfg.device);
+    if (B == 0) return POLAR_OK;
+    unsigned long long h[2] = {0, 0};
+    const int rc = fer_batch_impl(c, seed, first_frame, snr_db, B, h);
+    if (rc) return rc;
     *block_errors += h[0];
     *bit_errors += h[1];
     return POLAR_OK;
 }
+
+// ---- frames sharded over the GPUs of one node, RCCL only for the final reduction -------------------------------
+// RCCL is loaded on first use with dlopen (RTLD_LOCAL): the library has no link-time dependency on it, and a host process
+// that carries its own copy (torch does) is not disturbed.
+namespace {
+struct RcclApi {
+    void *handle = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+RcclApi &rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) return;
+        api.CommInitAll = (int (*)(void **, int, const int *))dlsym(api.handle, "ncclCommInitAll");
+        api.CommDestroy = (int (*)(void *))dlsym(api.handle, "ncclCommDestroy");
+        api.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(api.handle, "ncclAllReduce");
+        api.GroupStart = (int (*)())dlsym(api.handle, "ncclGroupStart");
+        api.GroupEnd = (int (*)())dlsym(api.handle, "ncclGroupEnd");
+        api.GetErrorString = (const char *(*)(int))dlsym(api.handle, "ncclGetErrorString");
+        api.ok = api.CommInitAll && api.CommDestroy && api.AllReduce && api.GroupStart && api.GroupEnd;
+    });
+    return api;
+}
+}  // namespace
+
+int polar_fer_multi_gpu(const polar_cfg *cfg, int ngpus, unsigned long long seed, unsigned long long first_frame, double snr_db,
+                        size_t frames_per_gpu, unsigned long long *block_errors, unsigned long long *bit_errors,
+                        double *seconds)
+{
+    if (!cfg || !block_errors || !bit_errors || ngpus < 1 || ngpus > 64) return POLAR_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ngpus > ndev) return POLAR_EDEVICE;
+    if (frames_per_gpu == 0) return POLAR_OK;
+    RcclApi &R = rccl();
+    if (!R.ok) return POLAR_EDEVICE;   // no RCCL on this machine
+    constexpr int ncclUint64_ = 5, ncclSum_ = 0;   // rccl.h: ncclDataType_t / ncclRedOp_t
+    std::vector<polar_ctx *> ctx((size_t)ngpus, nullptr);
+    std::vector<int> rcs((size_t)ngpus, POLAR_OK), devs((size_t)ngpus);
+    std::vector<double> secs((size_t)ngpus, 0.0);
+    for (int g = 0; g < ngpus; ++g) devs[(size_t)g] = g;
+    auto cleanup = [&](int rc) {
+        for (polar_ctx *c : ctx) polar_destroy(c);
+        return rc;
+    };
+    for (int g = 0; g < ngpus; ++g) {
+        polar_cfg one = *cfg;
+        one.device = g;
+        const int rc = polar_create(&one, &ctx[(size_t)g]);
+        if (rc) return cleanup(rc);
+    }
+    std::vector<void *> comms((size_t)ngpus, nullptr);
+    if (R.CommInitAll(comms.data(), ngpus, devs.data()) != 0) return cleanup(POLAR_EDEVICE);
+    // one host thread per GPU: its shard of the frame range, no data-path collective
+    {
+        std::vector<std::thread> th;
+        for (int g = 0; g < ngpus; ++g)
+            th.emplace_back([&, g] {
+                polar_ctx *c = ctx[(size_t)g];
+                DeviceGuard guard(g);
+                const auto t0 = std::chrono::steady_clock::now();
+                rcs[(size_t)g] = fer_batch_impl(c, seed, first_frame + (unsigned long long)g * frames_per_gpu, snr_db,
+                                                frames_per_gpu, nullptr);
+                if (rcs[(size_t)g] == POLAR_OK && hipStreamSynchronize(c->stream) != hipSuccess) rcs[(size_t)g] = POLAR_EDEVICE;
+                secs[(size_t)g] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            });
+        for (auto &t : th) t.join();
+    }
+    int rc = POLAR_OK;
+    for (int g = 0; g < ngpus; ++g)
+        if (rcs[(size_t)g]) rc = rcs[(size_t)g];
+    // the only exchange: sum of the two counters over the GPUs (16 bytes per rank over xGMI)
+    if (rc == POLAR_OK) {
+        bool bad = R.GroupStart() != 0;
+        for (int g = 0; g < ngpus && !bad; ++g) {
+            DeviceGuard guard(g);
+            void *buf = ctx[(size_t)g]->gen_cnt.p;
+            bad = R.AllReduce(buf, buf, 2, ncclUint64_, ncclSum_, comms[(size_t)g], ctx[(size_t)g]->stream) != 0;
+        }
+        bad = (R.GroupEnd() != 0) || bad;
+        if (bad) rc = POLAR_EDEVICE;
+    }
+    if (rc == POLAR_OK) {
+        unsigned long long h[2] = {0, 0};
+        DeviceGuard guard(0);
+        if (hipMemcpyAsync(h, ctx[0]->gen_cnt.p, 16, hipMemcpyDeviceToHost, ctx[0]->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx[0]->stream) != hipSuccess)
+            rc = POLAR_EDEVICE;
+        else {
+            *block_errors += h[0];
+            *bit_errors += h[1];
+        }
+        for (int g = 1; g < ngpus; ++g) {   // every rank holds the sum: drain the other streams before the buffers go away
+            DeviceGuard gg(g);
+            (void)hipStreamSynchronize(ctx[(size_t)g]->stream);
+        }
+    }
+    if (seconds) *seconds = *std::max_element(secs.begin(), secs.end());
+    for (void *cm : comms)
+        if (cm) (void)R.CommDestroy(cm);
+    return cleanup(rc);
+}
+
+
 
 // ---- include/polar_hip_testing.h ----------------------------------------------------------------------------
 int polar_testing_select_kernel(polar_ctx *c, int variant)

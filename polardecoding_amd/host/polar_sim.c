@@ -168,14 +168,14 @@ static const int CRC6[] = {0, 5, 6};
 static void usage(void)
 {
     fprintf(stderr, "usage: polar_sim --algo sc|bp|bpr|scl|cascl --N n --K k [--L l] [--crc 24c|6] [--sys] [--seed s] [--ble b]\n"
-                    "                 [--snr lo:hi:step | --snr-list a,b,..] [--batch b] [--dtype f64|f32] [--bp-iters i] [--q file] [--min-run m] [--fast]\n");
+                    "                 [--snr lo:hi:step | --snr-list a,b,..] [--batch b] [--dtype f64|f32] [--bp-iters i] [--q file] [--min-run m] [--fast [--gpus g]]\n");
     exit(2);
 }
 
 int main(int argc, char **argv)
 {
     int N = 1024, K = 512, L = 8, algo = POLAR_ALGO_CASCL, ble = 100, batch = 4096, dtype = POLAR_F64, bp_iters = 100;
-    int fast = 0, sys = 0, bpr = 0;
+    int fast = 0, sys = 0, bpr = 0, gpus = 1;
     long min_run = 0;   /* --min-run m: `errBlock < BLE || run < m`, the rule of the published L = 32 logs (m = 2000) */
     uint64_t seed = 1024;
     double lo = 1.0, hi = 3.0, step = 0.5;
@@ -202,6 +202,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--q") && v) { qfile = v; i++; }
         else if (!strcmp(a, "--min-run") && v) { min_run = atol(v); i++; }
         else if (!strcmp(a, "--fast")) { fast = 1; }
+        else if (!strcmp(a, "--gpus") && v) { gpus = atoi(v); i++; }   /* --fast only: frames sharded over the GPUs of the node */
         else if (!strcmp(a, "--sys")) { sys = 1; }
         else if (!strcmp(a, "--dtype") && v) { dtype = !strcmp(v, "f32") ? POLAR_F32 : POLAR_F64; i++; }
         else if (!strcmp(a, "--snr-list") && v) {
@@ -277,6 +278,13 @@ int main(int argc, char **argv)
             const double db = pts[ip];
             unsigned long long blk = 0, bits = 0, run = 0;
             while (blk < (unsigned long long)ble) {
+                if (gpus > 1) {   /* `batch` frames per GPU and round; one RCCL all-reduce of the two counters per round */
+                    rc = polar_fer_multi_gpu(&cfg, gpus, seed, first, db, (size_t)batch, &blk, &bits, NULL);
+                    if (rc) { fprintf(stderr, "fer_multi_gpu: %s\n", polar_strerror(rc)); return 1; }
+                    first += (unsigned long long)batch * (unsigned long long)gpus;
+                    run += (unsigned long long)batch * (unsigned long long)gpus;
+                    continue;
+                }
                 rc = polar_fer_batch(ctx, seed, first, db, (size_t)batch, &blk, &bits);
                 if (rc) { fprintf(stderr, "fer_batch: %s (%s)\n", polar_strerror(rc), polar_last_error(ctx)); return 1; }
                 first += (unsigned long long)batch;

@@ -180,3 +180,19 @@ def test_polar_sim_fast_mode_fer_curve():
         fer, r = blk / run, ref[snr]
         sig = math.sqrt(r * (1 - r) / run + r * r / 100)
         assert abs(fer - r) < 4 * sig, (snr, fer, r)
+
+
+def test_fer_multi_gpu_entry_point_on_the_gpus_present():
+    """polar_fer_multi_gpu (frames sharded over the node's GPUs, RCCL all-reduce of the two counters): with the GPUs this box
+    has (one on the test box: RCCL initialises a one-rank communicator) the totals equal polar_fer_batch over the same
+    frame range; asking for more GPUs than there are is an error code, not a crash."""
+    import torch
+    import polardecoding_amd as pa
+    dec = pa.CASCL(1024, 512, L=8)
+    n = torch.cuda.device_count()
+    per = 8192
+    want = dec.fer_batch(99, 1000, 1.5, per * n)
+    blk, bits, sec = dec.fer_multi_gpu(n, 99, 1000, 1.5, per)
+    assert (blk, bits) == want and blk > 100 and sec > 0
+    with pytest.raises(pa.PolarError):
+        dec.fer_multi_gpu(n + 1, 99, 1000, 1.5, per)
