@@ -172,9 +172,18 @@ int polar_fer_batch(polar_ctx *ctx, unsigned long long seed, unsigned long long 
 /* The same over the GPUs of one node (frames are independent, so the range first_frame .. first_frame +
  * ngpus * frames_per_gpu is cut into contiguous shards, one per GPU, each decoded by its own context on its own host thread;
  * no data-path collective).  The only exchange is the sum of the two counters, one ncclAllReduce of 2 x uint64 over RCCL /
- * xGMI, which is loaded with dlopen() on first use (POLAR_EDEVICE if the machine has none or fewer than ngpus devices).
- * Frame f of the range is the same frame whatever ngpus is (counter-based generator): the totals equal polar_fer_batch over
- * the whole range on one GPU.  seconds (nullable): the slowest GPU's time for its shard. */
+ * xGMI per call; RCCL is loaded with dlopen() on first use (POLAR_EDEVICE if the machine has none or fewer than ngpus
+ * devices).  Frame f of the range is the same frame whatever ngpus is (counter-based generator): the totals equal
+ * polar_fer_batch over the whole range on one GPU.  seconds (nullable): the slowest GPU's time for its shard.
+ * A polar_group holds the ngpus contexts (devices 0 .. ngpus-1; cfg->device is ignored) and the RCCL communicators, so that a
+ * sweep pays for their creation once; polar_fer_multi_gpu is create + one batch + destroy. */
+typedef struct polar_group polar_group;
+int polar_group_create(const polar_cfg *cfg, int ngpus, polar_group **out);
+void polar_group_destroy(polar_group *grp);
+int polar_group_size(const polar_group *grp);
+int polar_group_fer_batch(polar_group *grp, unsigned long long seed, unsigned long long first_frame, double snr_db,
+                          size_t frames_per_gpu, unsigned long long *block_errors, unsigned long long *bit_errors,
+                          double *seconds);
 int polar_fer_multi_gpu(const polar_cfg *cfg, int ngpus, unsigned long long seed, unsigned long long first_frame,
                         double snr_db, size_t frames_per_gpu, unsigned long long *block_errors,
                         unsigned long long *bit_errors, double *seconds);

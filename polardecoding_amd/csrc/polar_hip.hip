@@ -1167,84 +1167,127 @@ RcclApi &rccl()
 }
 }  // namespace
 
-int polar_fer_multi_gpu(const polar_cfg *cfg, int ngpus, unsigned long long seed, unsigned long long first_frame, double snr_db,
-                        size_t frames_per_gpu, unsigned long long *block_errors, unsigned long long *bit_errors,
-                        double *seconds)
+struct polar_group {
+    std::vector<polar_ctx *> ctx;
+    std::vector<void *> comms;   // ncclComm_t per GPU
+};
+
+void polar_group_destroy(polar_group *g)
 {
-    if (!cfg || !block_errors || !bit_errors || ngpus < 1 || ngpus > 64) return POLAR_EINVAL;
+    if (!g) return;
+    RcclApi &R = rccl();
+    for (void *cm : g->comms)
+        if (cm && R.ok) (void)R.CommDestroy(cm);
+    for (polar_ctx *c : g->ctx) polar_destroy(c);
+    delete g;
+}
+
+int polar_group_create(const polar_cfg *cfg, int ngpus, polar_group **out)
+{
+    if (!cfg || !out || ngpus < 1 || ngpus > 64) return POLAR_EINVAL;
+    *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ngpus > ndev) return POLAR_EDEVICE;
-    if (frames_per_gpu == 0) return POLAR_OK;
     RcclApi &R = rccl();
     if (!R.ok) return POLAR_EDEVICE;   // no RCCL on this machine
-    constexpr int ncclUint64_ = 5, ncclSum_ = 0;   // rccl.h: ncclDataType_t / ncclRedOp_t
-    std::vector<polar_ctx *> ctx((size_t)ngpus, nullptr);
-    std::vector<int> rcs((size_t)ngpus, POLAR_OK), devs((size_t)ngpus);
-    std::vector<double> secs((size_t)ngpus, 0.0);
-    for (int g = 0; g < ngpus; ++g) devs[(size_t)g] = g;
-    auto cleanup = [&](int rc) {
-        for (polar_ctx *c : ctx) polar_destroy(c);
-        return rc;
-    };
-    for (int g = 0; g < ngpus; ++g) {
+    polar_group *g = new (std::nothrow) polar_group();
+    if (!g) return POLAR_ENOMEM;
+    g->ctx.assign((size_t)ngpus, nullptr);
+    g->comms.assign((size_t)ngpus, nullptr);
+    std::vector<int> devs((size_t)ngpus);
+    for (int i = 0; i < ngpus; ++i) {
+        devs[(size_t)i] = i;
         polar_cfg one = *cfg;
-        one.device = g;
-        const int rc = polar_create(&one, &ctx[(size_t)g]);
-        if (rc) return cleanup(rc);
+        one.device = i;
+        const int rc = polar_create(&one, &g->ctx[(size_t)i]);
+        if (rc) {
+            polar_group_destroy(g);
+            return rc;
+        }
     }
-    std::vector<void *> comms((size_t)ngpus, nullptr);
-    if (R.CommInitAll(comms.data(), ngpus, devs.data()) != 0) return cleanup(POLAR_EDEVICE);
+    if (R.CommInitAll(g->comms.data(), ngpus, devs.data()) != 0) {
+        polar_group_destroy(g);
+        return POLAR_EDEVICE;
+    }
+    *out = g;
+    return POLAR_OK;
+}
+
+int polar_group_size(const polar_group *g) { return g ? (int)g->ctx.size() : 0; }
+
+int polar_group_fer_batch(polar_group *g, unsigned long long seed, unsigned long long first_frame, double snr_db,
+                          size_t frames_per_gpu, unsigned long long *block_errors, unsigned long long *bit_errors,
+                          double *seconds)
+{
+    if (!g || !block_errors || !bit_errors) return POLAR_EINVAL;
+    if (frames_per_gpu == 0) return POLAR_OK;
+    RcclApi &R = rccl();
+    constexpr int ncclUint64_ = 5, ncclSum_ = 0;   // rccl.h: ncclDataType_t / ncclRedOp_t
+    const int ngpus = (int)g->ctx.size();
+    std::vector<int> rcs((size_t)ngpus, POLAR_OK);
+    std::vector<double> secs((size_t)ngpus, 0.0);
     // one host thread per GPU: its shard of the frame range, no data-path collective
     {
         std::vector<std::thread> th;
-        for (int g = 0; g < ngpus; ++g)
-            th.emplace_back([&, g] {
-                polar_ctx *c = ctx[(size_t)g];
-                DeviceGuard guard(g);
+        for (int i = 0; i < ngpus; ++i)
+            th.emplace_back([&, i] {
+                polar_ctx *c = g->ctx[(size_t)i];
+                DeviceGuard guard(i);
                 const auto t0 = std::chrono::steady_clock::now();
-                rcs[(size_t)g] = fer_batch_impl(c, seed, first_frame + (unsigned long long)g * frames_per_gpu, snr_db,
+                rcs[(size_t)i] = fer_batch_impl(c, seed, first_frame + (unsigned long long)i * frames_per_gpu, snr_db,
                                                 frames_per_gpu, nullptr);
-                if (rcs[(size_t)g] == POLAR_OK && hipStreamSynchronize(c->stream) != hipSuccess) rcs[(size_t)g] = POLAR_EDEVICE;
-                secs[(size_t)g] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (rcs[(size_t)i] == POLAR_OK && hipStreamSynchronize(c->stream) != hipSuccess) rcs[(size_t)i] = POLAR_EDEVICE;
+                secs[(size_t)i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             });
         for (auto &t : th) t.join();
     }
     int rc = POLAR_OK;
-    for (int g = 0; g < ngpus; ++g)
-        if (rcs[(size_t)g]) rc = rcs[(size_t)g];
+    for (int i = 0; i < ngpus; ++i)
+        if (rcs[(size_t)i]) rc = rcs[(size_t)i];
     // the only exchange: sum of the two counters over the GPUs (16 bytes per rank over xGMI)
     if (rc == POLAR_OK) {
         bool bad = R.GroupStart() != 0;
-        for (int g = 0; g < ngpus && !bad; ++g) {
-            DeviceGuard guard(g);
-            void *buf = ctx[(size_t)g]->gen_cnt.p;
-            bad = R.AllReduce(buf, buf, 2, ncclUint64_, ncclSum_, comms[(size_t)g], ctx[(size_t)g]->stream) != 0;
+        for (int i = 0; i < ngpus && !bad; ++i) {
+            DeviceGuard guard(i);
+            void *buf = g->ctx[(size_t)i]->gen_cnt.p;
+            bad = R.AllReduce(buf, buf, 2, ncclUint64_, ncclSum_, g->comms[(size_t)i], g->ctx[(size_t)i]->stream) != 0;
         }
         bad = (R.GroupEnd() != 0) || bad;
         if (bad) rc = POLAR_EDEVICE;
     }
     if (rc == POLAR_OK) {
         unsigned long long h[2] = {0, 0};
-        DeviceGuard guard(0);
-        if (hipMemcpyAsync(h, ctx[0]->gen_cnt.p, 16, hipMemcpyDeviceToHost, ctx[0]->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx[0]->stream) != hipSuccess)
-            rc = POLAR_EDEVICE;
-        else {
+        {
+            DeviceGuard guard(0);
+            if (hipMemcpyAsync(h, g->ctx[0]->gen_cnt.p, 16, hipMemcpyDeviceToHost, g->ctx[0]->stream) != hipSuccess ||
+                hipStreamSynchronize(g->ctx[0]->stream) != hipSuccess)
+                rc = POLAR_EDEVICE;
+        }
+        for (int i = 1; i < ngpus; ++i) {   // every rank holds the sum: drain the other streams before the next call reuses the buffers
+            DeviceGuard gg(i);
+            if (hipStreamSynchronize(g->ctx[(size_t)i]->stream) != hipSuccess) rc = POLAR_EDEVICE;
+        }
+        if (rc == POLAR_OK) {
             *block_errors += h[0];
             *bit_errors += h[1];
         }
-        for (int g = 1; g < ngpus; ++g) {   // every rank holds the sum: drain the other streams before the buffers go away
-            DeviceGuard gg(g);
-            (void)hipStreamSynchronize(ctx[(size_t)g]->stream);
-        }
     }
     if (seconds) *seconds = *std::max_element(secs.begin(), secs.end());
-    for (void *cm : comms)
-        if (cm) (void)R.CommDestroy(cm);
-    return cleanup(rc);
+    return rc;
 }
 
-
+int polar_fer_multi_gpu(const polar_cfg *cfg, int ngpus, unsigned long long seed, unsigned long long first_frame, double snr_db,
+                        size_t frames_per_gpu, unsigned long long *block_errors, unsigned long long *bit_errors,
+                        double *seconds)
+{
+    if (!block_errors || !bit_errors) return POLAR_EINVAL;
+    polar_group *g = nullptr;
+    int rc = polar_group_create(cfg, ngpus, &g);
+    if (rc) return rc;
+    rc = polar_group_fer_batch(g, seed, first_frame, snr_db, frames_per_gpu, block_errors, bit_errors, seconds);
+    polar_group_destroy(g);
+    return rc;
+}
 
 // ---- include/polar_hip_testing.h ----------------------------------------------------------------------------
 int polar_testing_select_kernel(polar_ctx *c, int variant)

@@ -274,13 +274,18 @@ int main(int argc, char **argv)
     printf("SEED = %llu\n", (unsigned long long)seed);
     if (fast) {
         unsigned long long first = 0;
+        polar_group *grp = NULL;   /* --gpus N: one context per GPU + the RCCL communicators, made once for the sweep */
+        if (gpus > 1 && (rc = polar_group_create(&cfg, gpus, &grp)) != 0) {
+            fprintf(stderr, "polar_group_create(%d GPUs): %s\n", gpus, polar_strerror(rc));
+            return 1;
+        }
         for (int ip = 0; ip < npts; ip++) {
             const double db = pts[ip];
             unsigned long long blk = 0, bits = 0, run = 0;
             while (blk < (unsigned long long)ble) {
                 if (gpus > 1) {   /* `batch` frames per GPU and round; one RCCL all-reduce of the two counters per round */
-                    rc = polar_fer_multi_gpu(&cfg, gpus, seed, first, db, (size_t)batch, &blk, &bits, NULL);
-                    if (rc) { fprintf(stderr, "fer_multi_gpu: %s\n", polar_strerror(rc)); return 1; }
+                    rc = polar_group_fer_batch(grp, seed, first, db, (size_t)batch, &blk, &bits, NULL);
+                    if (rc) { fprintf(stderr, "polar_group_fer_batch: %s\n", polar_strerror(rc)); return 1; }
                     first += (unsigned long long)batch * (unsigned long long)gpus;
                     run += (unsigned long long)batch * (unsigned long long)gpus;
                     continue;
@@ -294,6 +299,7 @@ int main(int argc, char **argv)
                    (double)blk / (double)run, (double)bits / (double)run / (double)(c.sys ? c.K : c.A));
             fflush(stdout);
         }
+        polar_group_destroy(grp);
         polar_destroy(ctx);
         return 0;
     }

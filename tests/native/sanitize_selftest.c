@@ -23,9 +23,11 @@ const char *polar_last_error(const polar_ctx *a) { (void)a; return ""; }
 int polar_info_order(const polar_ctx *a, int *b, int c) { (void)a; (void)b; (void)c; return POLAR_EDEVICE; }
 int polar_fer_batch(polar_ctx *a, unsigned long long b, unsigned long long c, double d, size_t e, unsigned long long *f,
                     unsigned long long *g) { (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; return POLAR_EDEVICE; }
-int polar_fer_multi_gpu(const polar_cfg *a, int b, unsigned long long c, unsigned long long d, double e, size_t f,
-                        unsigned long long *g, unsigned long long *h, double *i)
-{ (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; return POLAR_EDEVICE; }
+int polar_group_create(const polar_cfg *a, int b, polar_group **c) { (void)a; (void)b; (void)c; return POLAR_EDEVICE; }
+void polar_group_destroy(polar_group *a) { (void)a; }
+int polar_group_fer_batch(polar_group *a, unsigned long long c, unsigned long long d, double e, size_t f,
+                          unsigned long long *g, unsigned long long *h, double *i)
+{ (void)a; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; return POLAR_EDEVICE; }
 int polar_stop_rule_batch_y(polar_ctx *a, const double *b, double c, const uint32_t *d, size_t e, unsigned f, size_t g,
                             size_t *h, unsigned long long *i, unsigned long long *j)
 { (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; (void)j; return POLAR_EDEVICE; }

@@ -196,3 +196,10 @@ def test_fer_multi_gpu_entry_point_on_the_gpus_present():
     assert (blk, bits) == want and blk > 100 and sec > 0
     with pytest.raises(pa.PolarError):
         dec.fer_multi_gpu(n + 1, 99, 1000, 1.5, per)
+    # the C harness on the same entry points: --gpus 1 prints what the single-context path prints
+    import os, subprocess
+    sim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "polardecoding_amd", "lib", "polar_sim")
+    args = [sim, "--algo", "cascl", "--N", "1024", "--K", "512", "--L", "8", "--crc", "24c", "--fast", "--batch", "32768",
+            "--ble", "100", "--snr", "1.5:1.5:0.5", "--seed", "5"]
+    a = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0 and "error block" in a.stdout
