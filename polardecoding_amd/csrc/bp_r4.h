@@ -7,7 +7,9 @@
 // thread and lives in its registers for the whole decode.  Only the rows that cross a group boundary (R[2], R[4], R[6],
 // R[8], L[2], L[4], L[6], L[8]) go through LDS: 64 KB per codeword in f64 instead of 152 KB -> two codewords per CU, each
 // thread with two independent butterflies in flight per stage, 2.7 message accesses per butterfly instead of 6, and no
-// per-stage index arithmetic (the element sets are compile-time functions of the group).
+// per-stage index arithmetic (the element sets are compile-time functions of the group).  The four L rows are read from
+// LDS once per iteration and kept in the reader's registers for the next right-going sweep, so they share ONE transfer
+// row: 40 KB per codeword, three f64 codewords per CU (LCACHE below).
 //
 // Threads: 256 per codeword, t = 64 w + x.  Group g < 4 removes element bits 2g, 2g+1, which are below bit 8: wave w works
 // on elements [256 w, 256 w + 256) in all of them, so groups 0..3 hand rows over inside one wave (LDS executes a wave's
@@ -35,7 +37,16 @@ namespace polar {
 template <typename R>
 struct BpR4Cfg {
     static constexpr int N = 1024, n = 10, NW = 32, THREADS = 256;
-    static constexpr size_t rows_bytes = sizeof(R) * (size_t)N * 8;          // R2 R4 R6 R8 L2 L4 L6 L8
+#ifndef POLAR_BPR4_LCACHE
+#define POLAR_BPR4_LCACHE 1
+#endif
+    // LCACHE: the rows L[2], L[4], L[6], L[8] are read from LDS once per iteration (by the left-going sweep), kept in the
+    // reader's registers for the right-going sweep of the next iteration, and so only need ONE transfer row in LDS:
+    // 40 KB per codeword instead of 64 KB -> three f64 codewords per CU, no LDS initialisation per frame.
+    static constexpr bool LCACHE = POLAR_BPR4_LCACHE != 0;
+    static constexpr int LROWS = LCACHE ? 1 : 4;
+    static constexpr int MIN_BLOCKS = LCACHE ? 3 : 2;
+    static constexpr size_t rows_bytes = sizeof(R) * (size_t)N * (4 + LROWS);   // R2 R4 R6 R8, then L2 L4 L6 L8 (or the one transfer row)
     static constexpr size_t off_lut = rows_bytes;
     static constexpr size_t off_dn = off_lut + ((Lut<R>::bytes + 15) / 16) * 16;
     static constexpr size_t off_st = off_dn + sizeof(R) * 64;
@@ -47,6 +58,7 @@ struct BpR4 {
     using C = BpR4Cfg<R>;
     static constexpr int N = C::N;
     R Ri[5][4], Li[5][4];   // interior rows R[2g+1], L[2g+1] at this thread's elements of group g
+    R Lb[4][4];             // LCACHE: L[2g+2] at this thread's elements of group g, as read by the last left-going sweep
     R ch[4];                // channel LLRs at the group-4 elements
     R *rowR, *rowL;         // LDS: rowR + (g-1) N = R[2g], rowL + (g-1) N = L[2g], g = 1..4
     Lut<R> lut;
@@ -108,7 +120,7 @@ struct BpR4 {
             // stage 2G+1: r[2G+1], l[2G+2] -> r[2G+2]
             R lin[4], o[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) lin[k] = rowL[G * N + e + k * s];
+            for (int k = 0; k < 4; ++k) lin[k] = C::LCACHE ? Lb[G][k] : rowL[G * N + e + k * s];
             bfR(Ri[G][0], Ri[G][2], lin[0], lin[2], o[0], o[2]);
             bfR(Ri[G][1], Ri[G][3], lin[1], lin[3], o[1], o[3]);
 #pragma unroll
@@ -125,7 +137,11 @@ struct BpR4 {
         const int e = e0<G>();
         R lin[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) lin[k] = (G == 4) ? ch[k] : rowL[G * N + e + k * s];
+        for (int k = 0; k < 4; ++k) lin[k] = (G == 4) ? ch[k] : rowL[(C::LCACHE ? 0 : G * N) + e + k * s];
+        if constexpr (C::LCACHE && G < 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Lb[G][k] = lin[k];
+        }
         // stage 2G+1: l[2G+2], r[2G+1] -> l[2G+1]
         bfL(lin[0], lin[2], Ri[G][0], Ri[G][2], Li[G][0], Li[G][2]);
         bfL(lin[1], lin[3], Ri[G][1], Ri[G][3], Li[G][1], Li[G][3]);
@@ -137,7 +153,7 @@ struct BpR4 {
             bfL(Li[G][0], Li[G][1], rin[0], rin[1], o[0], o[1]);
             bfL(Li[G][2], Li[G][3], rin[2], rin[3], o[2], o[3]);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rowL[(G - 1) * N + e + k * s] = o[k];
+            for (int k = 0; k < 4; ++k) rowL[(C::LCACHE ? 0 : (G - 1) * N) + e + k * s] = o[k];
         } else if constexpr (LAST) {
             // stage 0, needed only for the decision (BP_1024.c:417-425): frozen -> 0, else (l[0] + r[0] >= 0) -> 0
             R o[4];
@@ -154,7 +170,7 @@ struct BpR4 {
 __device__ __forceinline__ void bp_wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 template <typename R, typename IN>
-__global__ __launch_bounds__(256, 2) void k_bp_r4(BpParams P)
+__global__ __launch_bounds__(256, (BpR4Cfg<R>::MIN_BLOCKS)) void k_bp_r4(BpParams P)
 {
     using C = BpR4Cfg<R>;
     constexpr int N = C::N, NW = C::NW;
@@ -189,9 +205,12 @@ __global__ __launch_bounds__(256, 2) void k_bp_r4(BpParams P)
             for (int k = 0; k < 4; ++k) {
                 s.Ri[g][k] = R(0);   // BP_1024.c:384-386
                 s.Li[g][k] = R(0);   // :378-380
+                if (g < 4) s.Lb[g][k] = R(0);
             }
-        for (int i = s.t; i < 8 * N; i += 256) s.rowR[i] = R(0);
-        __syncthreads();
+        if constexpr (!C::LCACHE) {   // the L rows in LDS are read by the first right-going sweep before anything wrote them
+            for (int i = s.t; i < 8 * N; i += 256) s.rowR[i] = R(0);
+            __syncthreads();
+        }
 
         uint32_t bits = 0;
         for (int it = 0; it < P.iters; ++it) {
