@@ -111,3 +111,35 @@ def test_bench_under_torchrun_single_rank():
         assert key in d, key
     assert d["scaling"] == "weak" and d["dtype"] == "f64" and d["roofline"]["bound"] == "hbm"
     assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_two_host_threads_two_contexts(oracle):
+    """A ctx is not re-entrant, but two contexts on two host threads are independent (own stream, own scratch): both decode
+    concurrently on the same GPU and both get the oracle's decisions; the calling thread's current device is left alone."""
+    import threading
+    import torch
+    import polardecoding_amd as pa
+    code = oracle.Code(1024, 512, oracle.CRC24C_TAPS)
+    sig = oracle.sigma_from_db(1.5)
+    _, ys = oracle.Sim(4).frames(code, sig, 40)
+    llr = np.stack([oracle.llr_from_y(y, sig) for y in ys])
+    ref, ref_pm, _ = oracle.decode(code, llr, "CASCL", L=8)
+    big = np.tile(llr, (400, 1))                      # 16 000 frames per call: the two threads really overlap
+    out = [None, None]
+    dev_before = torch.cuda.current_device()
+
+    def work(i):
+        dec = pa.CASCL(1024, 512, L=8)
+        for _ in range(3):
+            uh, pm, _ = dec.decode_batch(big)
+        out[i] = (uh, pm)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert torch.cuda.current_device() == dev_before
+    for uh, pm in out:
+        assert np.array_equal(uh.reshape(400, 40, 1024), np.broadcast_to(ref, (400, 40, 1024)))
+        assert np.array_equal(pm.reshape(400, 40), np.broadcast_to(ref_pm, (400, 40)))
