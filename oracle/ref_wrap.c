@@ -9,6 +9,10 @@
  *   -DREF_DECODE=CASCL                                  its decode entry point
  *   -DREF_KIND=3                                        0 SC, 1 BP, 2 SCL, 3 CASCL, 4 BP with per-stage read-outs (BPr_128.c)
  *   -DREF_BITREV                                        the program decodes on the bit-reversed graph (CASCL_1024_sys.c)
+ *   -DREF_DROPIN -DREF_TAPS=0,5,6                       drop-in demonstration (oracle/Makefile target `dropin`): REF_SRC is the
+ *                                                       program streamed through sed with the ONE decode call of its main()
+ *                                                       reading ref_dropin(y, u_hat) -- the binding of INTEGRATION.md 2 --
+ *                                                       so the reference's own main() runs on libpolar_hip.so
  *
  * What is restated here (because the reference keeps it inline in main(), SCL_1024.c:159-217) is
  * only the graph/frozen-set SET-UP, done with the reference's own connectBCB() and Q table.
@@ -52,6 +56,10 @@ static int ref_printf(const char *fmt, ...)
     va_end(ap);
     return rv;
 }
+#ifdef REF_DROPIN
+#include "polar_hip.h"
+static void ref_dropin(double *y, int *u_hat);   /* defined below, once the program's N, K, L, r, I[] and std are known */
+#endif
 #define printf ref_printf
 #define time(x) ((time_t)ref_time_value)
 #define scanf(fmt, p) ref_scanf_int(p)
@@ -78,6 +86,40 @@ enum { REF_CRC = 0 };
 #endif
 
 static int ref_ready = 0;
+
+#ifdef REF_DROPIN
+/* What INTEGRATION.md 2 tells a maintainer to add: a context made from the program's own constants and its I[] (filled by
+ * main() before the first frame), and polar_decode() in place of the decode call. */
+static void ref_dropin(double *y, int *u_hat)
+{
+    static polar_ctx *ctx = NULL;
+    if (!ctx) {
+#ifdef REF_TAPS
+        static const int taps[] = {REF_TAPS};
+#endif
+        /* positional initialiser: the program's N, K, L, r are macros here, so the fields cannot be named
+         * { N, K, crc_r, crc_taps, n_taps, L, algo, bp_iters, info_order, dtype, device, crc_systematic } */
+        polar_cfg cfg = {REF_BLOCK, REF_INFO, REF_CRC,
+#ifdef REF_TAPS
+                         taps, (int)(sizeof taps / sizeof taps[0]),
+#else
+                         NULL, 0,
+#endif
+                         REF_LIST,
+                         REF_KIND == 0 ? POLAR_ALGO_SC : REF_KIND == 1 ? POLAR_ALGO_BP : REF_KIND == 2 ? POLAR_ALGO_SCL : POLAR_ALGO_CASCL,
+#if REF_KIND == 1
+                         iterMax,
+#else
+                         0,
+#endif
+                         I, POLAR_F64, 0, 0};
+        int rc;
+        rc = polar_create(&cfg, &ctx);
+        if (rc) { fprintf(stderr, "polar_create: %s\n", polar_strerror(rc)); exit(1); }
+    }
+    if (polar_decode(ctx, y, std, u_hat) != POLAR_OK) { fprintf(stderr, "polar_decode: %s\n", polar_last_error(ctx)); exit(1); }
+}
+#endif
 
 int ref_block_length(void) { return REF_BLOCK; }
 int ref_info_bits(void) { return REF_INFO; }
