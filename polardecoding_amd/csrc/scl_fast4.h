@@ -87,9 +87,13 @@ struct Fast4Dec {
     __device__ __forceinline__ void set_pa(int t, int v) { ptr = (ptr & ~(7u << (3 * (t - 4)))) | ((uint32_t)v << (3 * (t - 4))); }
     __device__ __forceinline__ int pb(int t) const { return (ptr >> (3 * (NFA + t - 5))) & 7; }
     __device__ __forceinline__ void set_pb(int t, int v) { ptr = (ptr & ~(7u << (3 * (NFA + t - 5)))) | ((uint32_t)v << (3 * (NFA + t - 5))); }
+#ifndef POLAR_F4_WIDE_LUT1
+#define POLAR_F4_WIDE_LUT1 0
+#endif
+    // wide steps: the compact two-round-trip form (the one-round-trip form, POLAR_F4_WIDE_LUT1=1, measured 13.0 -> 19.5 ms: spills)
     __device__ __forceinline__ R chk(R a, R b) const
     {
-        if constexpr (sizeof(R) == 4) return chk_lut1<R>(a, b, lut);
+        if constexpr (sizeof(R) == 4 || (POLAR_F4_WIDE_LUT1 != 0)) return chk_lut1<R>(a, b, lut);
         else return chk_lut<R>(a, b, lut);
     }
     __device__ __forceinline__ R chks(R a, R b) const { return chk_lut1<R>(a, b, lut); }
@@ -531,6 +535,113 @@ struct Fast4Dec {
         set_bit_k<K>(o, bit);
     }
 
+    // ---- the leading run of P all-frozen octets (leaves 0 .. 8P-1; 1 <= P <= 15), instead of octets 0 .. P-1 ----
+    // As in k_scl_fast2: nothing has been decided, every partial sum is 0, so both children of every node are known as
+    // soon as the node is (f(x, y) and y + x): the first 128-leaf subtree is evaluated as seven butterfly stages over one
+    // 128-element LDS array per codeword (16 lanes, four butterflies per lane and stage), levels 8 and 7 above it once per
+    // codeword into slot 0's scratch rows (every slot points there), the metric adds PHI(lambda_j, 0) in leaf order
+    // (SCL_1024.c:601-604), and the registers are loaded with the nodes that contain leaf 8P at levels 4..6.
+    __device__ __forceinline__ void frozen_prefix(int P)
+    {
+        const int w16 = p * 2 + pos, j0 = 8 * P;
+        vm_drain();   // the top-left level written by the root step
+        {
+            const R *tl = tls();
+            // slot 0's rows of this codeword in the lane-interleaved layout: element e belongs to lane c*2 + (e & 1)
+            auto slot0 = [&](size_t base, int e) -> R * {
+                return scr + fresh((unsigned)(base + at(e >> 6, (e & 63) >> 1) + c * 2 + (e & 1)));
+            };
+            R v8[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int e = w16 + 16 * k;
+                v8[k] = chk(ld_sc(tl + e), ld_sc(tl + e + 256));
+                *slot0(C::sc_l8, e) = v8[k];
+            }
+            lds_fence();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const R v7 = chk(v8[k], v8[k + 8]);   // elements e and e + 128 of level 8
+                *slot0(C::sc_l7, w16 + 16 * k) = v7;
+                stg[w16 + 16 * k] = v7;
+            }
+            set_pa(8, 0);
+            set_pa(7, 0);
+        }
+        lds_fence();
+#pragma unroll
+        for (int t = 6; t >= 0; --t) {
+            const int h = 1 << t;
+            int idx[4];
+            R x[4], y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = w16 + 16 * i;
+                idx[i] = ((b >> t) << (t + 1)) | (b & (h - 1));
+                x[i] = stg[idx[i]];
+                y[i] = stg[idx[i] + h];
+            }
+            lds_fence();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                stg[idx[i]] = chk(x[i], y[i]);
+                stg[idx[i] + h] = y[i] + x[i];
+            }
+            lds_fence();
+            if (t >= 4) {   // node of level t that holds leaf j0: elements pos + 2r
+                const R *node = stg + ((j0 >> t) << t) + pos;
+#pragma unroll
+                for (int r = 0; r < h / 2; ++r) A[h / 2 + r] = node[2 * r];
+            }
+        }
+        // PHI(lambda_j, 0) of all 128 leaves, then the metric in leaf order
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const R lam = stg[w16 + 16 * k];
+            stg[128 + w16 + 16 * k] = lut.tabv(lam) + negmax(lam);
+        }
+        lds_fence();
+        R pm = PM;
+#pragma unroll 8
+        for (int j = 0; j < j0; ++j) pm += stg[128 + j];
+        PM = pm;
+        lds_fence();
+    }
+
+    // ---- octets whose first seven leaves are frozen: breadth-first (all partner bits are 0, every g is cL + cU) ----
+    // Two level-1 nodes share each level-0 CHK: pos 0 evaluates f of one node, pos 1 f of the other.
+    __device__ __forceinline__ void octet_frozen_prefix(int o, bool last_frozen)
+    {
+        // level 2: f half (leaves 0..3) and g half (leaves 4..7), elements pos and pos + 2 each
+        const R xf0 = chks(A[4], A[6]), xf1 = chks(A[5], A[7]);
+        const R xg0 = A[6] + A[4], xg1 = A[7] + A[5];
+        // level 1: four nodes of two elements (element pos)
+        const R ff = chks(xf0, xf1), gf = xf1 + xf0;   // leaves 0-1, 2-3
+        const R fg = chks(xg0, xg1), gg = xg1 + xg0;   // leaves 4-5, 6-7
+        // level 0
+        const R pff = quadp<0xB1>(ff), pgf = quadp<0xB1>(gf), pfg = quadp<0xB1>(fg), pgg = quadp<0xB1>(gg);
+        const R la = chks(pos ? pgf : ff, pos ? gf : pff);       // pos 0: lambda_0, pos 1: lambda_2
+        const R lb = pos ? (gf + pgf) : (pff + ff);               // pos 0: lambda_1, pos 1: lambda_3
+        const R lc = chks(pos ? pgg : fg, pos ? gg : pfg);       // pos 0: lambda_4, pos 1: lambda_6
+        const R ld = pos ? (gg + pgg) : (pfg + fg);               // pos 0: lambda_5, pos 1: lambda_7
+        const R pa_ = lut.tabv(la) + negmax(la), pb_ = lut.tabv(lb) + negmax(lb);   // PHI(lambda_k, 0)
+        const R pc_ = lut.tabv(lc) + negmax(lc), pd_ = lut.tabv(ld) + negmax(ld);
+        PM += pa_;
+        PM += pb_;
+        PM += quadp<0xB1>(pa_);
+        PM += quadp<0xB1>(pb_);
+        PM += pc_;
+        PM += pd_;
+        PM += quadp<0xB1>(pc_);
+        bl0 &= ~0xFEu;
+        if (last_frozen) {
+            PM += quadp<0xB1>(pd_);
+            set_bit_tail(8 * o + 7, 0u);
+        } else {
+            decide<7>(o, false, quadp<0xB1>(ld));
+        }
+    }
+
     // ---- the 8 leaves of octet o; A[4..7] hold the level-3 LLRs ----
     __device__ __forceinline__ R lam0() const { return chks(a1, quadp<0xB1>(a1)); }                      // f0, valid at pos 0
     __device__ __forceinline__ R lam1() const { return g_bit<R>(a1, quadp<0xB1>(a1), bl0, 1); }          // g0
@@ -624,6 +735,14 @@ __global__ __launch_bounds__(256, (Fast4Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
     s.scr = reinterpret_cast<R *>(P.scratch) + (size_t)wave_global * C::scratch_elems;
     uint32_t *blw_wave = reinterpret_cast<uint32_t *>(base + C::off_bl);
 
+    // leading all-frozen octets (at most 15: the run must end inside the first 128-leaf subtree)
+    int lead = 0;
+    while (lead < 15 && ((frz[lead >> 2] >> (8 * (lead & 3))) & 0xFFu) == 0xFFu) ++lead;
+#ifdef POLAR_F4_NO_PREFIX
+    lead = 0;
+#endif
+    lead = __builtin_amdgcn_readfirstlane(lead);
+
     for (int quad = wave_global; CW * quad < P.B; quad += waves_total) {
         const int frame_raw = CW * quad + c;
         const bool live = frame_raw < P.B;
@@ -652,7 +771,14 @@ __global__ __launch_bounds__(256, (Fast4Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
         uint32_t fword = 0;
 
         STAMP(2);
-        for (int o = 0; o < N / 8; ++o) {
+        int o_first = 0;
+        if (lead > 0) {
+            s.frozen_prefix(lead);
+            STAMP(6);
+            o_first = lead;
+            fword = frz[o_first >> 2];
+        }
+        for (int o = o_first; o < N / 8; ++o) {
             if ((o & 3) == 0) fword = frz[o >> 2];
 #ifdef POLAR_STAMPS
             {
@@ -672,7 +798,11 @@ __global__ __launch_bounds__(256, (Fast4Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
             s.octet_head(o);
 #endif
             const uint32_t fm = (fword >> (8 * (o & 3))) & 0xFFu;
-            s.octet(o, fm);
+#ifndef POLAR_F4_NO_PREFIX
+            if ((fm & 0x7Fu) == 0x7Fu) s.octet_frozen_prefix(o, fm == 0xFFu);
+            else
+#endif
+                s.octet(o, fm);
             STAMP(5);
         }
 
