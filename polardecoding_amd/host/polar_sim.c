@@ -168,7 +168,7 @@ static const int CRC6[] = {0, 5, 6};
 static void usage(void)
 {
     fprintf(stderr, "usage: polar_sim --algo sc|bp|bpr|scl|cascl --N n --K k [--L l] [--crc 24c|6] [--sys] [--seed s] [--ble b]\n"
-                    "                 [--snr lo:hi:step | --snr-list a,b,..] [--batch b] [--dtype f64|f32] [--bp-iters i] [--q file] [--min-run m] [--fast [--gpus g]]\n");
+                    "                 [--snr lo:hi:step | --snr-list a,b,..] [--batch b] [--dtype f64|f32] [--bp-iters i] [--q file] [--fn file] [--min-run m] [--fast [--gpus g]]\n");
     exit(2);
 }
 
@@ -181,7 +181,7 @@ int main(int argc, char **argv)
     double lo = 1.0, hi = 3.0, step = 0.5;
     double pts[64];
     int npts = 0;   /* --snr-list a,b,c: explicit Eb/N0 points (the published L = 32 log goes 1.0, 1.5, 2.0, 2.2) */
-    const char *crc = NULL, *qfile = NULL;
+    const char *crc = NULL, *qfile = NULL, *fnfile = NULL;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
         const char *v = (i + 1 < argc) ? argv[i + 1] : NULL;
@@ -201,6 +201,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--bp-iters") && v) { bp_iters = atoi(v); i++; }
         else if (!strcmp(a, "--q") && v) { qfile = v; i++; }
         else if (!strcmp(a, "--min-run") && v) { min_run = atol(v); i++; }
+        else if (!strcmp(a, "--fn") && v) { fnfile = v; i++; }
         else if (!strcmp(a, "--fast")) { fast = 1; }
         else if (!strcmp(a, "--gpus") && v) { gpus = atoi(v); i++; }   /* --fast only: frames sharded over the GPUs of the node */
         else if (!strcmp(a, "--sys")) { sys = 1; }
@@ -234,6 +235,23 @@ int main(int argc, char **argv)
     }
     c.A = K + c.r;
     c.sys = sys && c.r > 0;
+    /* --fn file: the N x N generator matrix the reference reads from stdin (SCL_1024.c:207-217), read the same way: N*N
+       whitespace-separated integers, "Illegal input!" for anything but 0 / 1.  The encoder here (and the factor graph of
+       every decoder, the reference's included) is F^{(x)n}, Fn[i][j] = ((i & j) == j): any other matrix is refused. */
+    if (fnfile) {
+        FILE *ff = strcmp(fnfile, "-") ? fopen(fnfile, "r") : stdin;
+        if (!ff) { fprintf(stderr, "cannot open %s\n", fnfile); return 1; }
+        long bad = 0;
+        for (long i = 0; i < (long)N * N; i++) {
+            int temp;
+            if (fscanf(ff, "%d", &temp) != 1) { fprintf(stderr, "%s: fewer than %d x %d entries\n", fnfile, N, N); return 1; }
+            if (temp != 0 && temp != 1) printf("Illegal input!\n");
+            const int want = (((i / N) & (i % N)) == (i % N)) ? 1 : 0;
+            bad += (temp != want);
+        }
+        if (ff != stdin) fclose(ff);
+        if (bad) { fprintf(stderr, "%s: %ld entries differ from the Kronecker power of [1 0; 1 1]; not supported\n", fnfile, bad); return 1; }
+    }
     /* --q file: N whitespace-separated positions in ascending reliability (the shape of the reference's `const int Q[N]`
        literal, SC_1024.c:42-91); the information set is its last K + r entries, I[i] = Q[N-(K+r)+i] (CASCL_1024_L8.c:214-217) */
     int *qorder = NULL;

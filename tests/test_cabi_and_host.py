@@ -174,3 +174,31 @@ def test_bench_launches_its_own_ranks_under_gloo():
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--rehearse-cpu"],
                          capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0"))
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+
+
+def test_fn_matrix_file_format(tmp_path):
+    """The N x N 0/1 matrix the reference reads from stdin (SCL_1024.c:207-217): written, read back the reference's way,
+    recognised as the Kronecker power; a damaged copy is counted and rejected; its rows ARE the butterfly encoder."""
+    from polardecoding_amd import fnfile
+    p = tmp_path / "Fn_128.txt"
+    fnfile.write_fn(str(p), 128)
+    m, illegal = fnfile.read_fn(str(p))
+    assert m.shape == (128, 128) and illegal == 0 and fnfile.is_kronecker(m)
+    rng = np.random.default_rng(3)
+    u = rng.integers(0, 2, 128)
+    x = (u @ m) % 2                                   # x = u Fn, SCL_1024.c:242-250
+    y = u.copy()
+    s = 1
+    while s < 128:                                     # the butterfly form used by the harness and the generator kernel
+        for j in range(128):
+            if not (j & s):
+                y[j] ^= y[j + s]
+        s *= 2
+    assert np.array_equal(x, y)
+    txt = p.read_text().split()
+    txt[5] = "7"
+    txt[300] = "1" if txt[300] == "0" else "0"
+    q = tmp_path / "bad.txt"
+    q.write_text(" ".join(txt))
+    m2, illegal2 = fnfile.read_fn(str(q), 128)
+    assert illegal2 == 1 and not fnfile.is_kronecker(m2)

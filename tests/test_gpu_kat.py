@@ -125,3 +125,22 @@ def test_reliability_order_from_a_file(tmp_path):
     b, _ = run_sim(base + ["--q", str(q)])
     exp, _ = published("myResult_128/CASCL_128_L8.txt", 8392, 8, 3)
     assert a == b == exp
+
+
+def test_generator_matrix_from_a_file(tmp_path):
+    """--fn file: the N x N matrix the reference programs read from stdin (SCL_1024.c:207-217).  The Kronecker power is
+    accepted (same run counts as without it), anything else is refused with an error, not decoded wrongly."""
+    from polardecoding_amd import fnfile
+    fn = tmp_path / "Fn_128.txt"
+    fnfile.write_fn(str(fn), 128)
+    base = ["--algo", "sc", "--N", "128", "--K", "64", "--snr", "1.0:2.0:0.5", "--seed", "1024", "--ble", "100", "--batch", "512"]
+    a, _ = run_sim(base)
+    b, _ = run_sim(base + ["--fn", str(fn)])
+    exp, _ = published("myResult_128/SC128out.txt", 1024, 1, 3)
+    assert a == b == exp
+    txt = fn.read_text().split()
+    txt[129] = "0"                      # Fn[1][1] must be 1
+    bad = tmp_path / "bad.txt"
+    bad.write_text(" ".join(txt))
+    out = subprocess.run([SIM] + base + ["--fn", str(bad)], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "Kronecker" in out.stderr
