@@ -20,11 +20,18 @@ CURVES = [
     ("CA-SCL N=1024 K=512 CRC-24C L=8", "myResult_1024/CASCL_L8.dat", 8, ["--algo", "cascl", "--N", "1024", "--K", "512", "--L", "8", "--crc", "24c"], "1.0:2.5:0.5", 3000, 1 << 17),
     ("CA-SCL N=128 K=64 CRC-6 L=8", "myResult_128/CASCL_128_L8.txt", 8, ["--algo", "cascl", "--N", "128", "--K", "64", "--L", "8", "--crc", "6"], "1.0:3.5:0.5", 5000, 1 << 17),
     ("SCL N=128 K=64 L=8", "myResult_128/SCL128out_errblock50.dat", 8, ["--algo", "scl", "--N", "128", "--K", "64", "--L", "8"], "1.0:3.5:0.5", 5000, 1 << 17),
+    ("CA-SCL N=1024 K=512 CRC-24C L=32 (k_scl_big)", "myResult_1024/CASCL_L32.dat", 32, ["--algo", "cascl", "--N", "1024", "--K", "512", "--L", "32", "--crc", "24c"], "1.0,1.5,2.0,2.2", 2000, 1 << 15),
+    ("CA-SCL N=128 K=64 CRC-6 L=32", "myResult_128/CASCL_128_L32.txt", 32, ["--algo", "cascl", "--N", "128", "--K", "64", "--L", "32", "--crc", "6"], "1.0:3.5:0.5", 3000, 1 << 16),
+    # BP: the seed-labelled log myResult_1024.zip:BP1024out_NewSEED.dat (SEED 771, 200 errors per point, iterMax 100)
+    ("BP N=1024 K=512, 100 iterations (k_bp_r4)", {1.0: (200, 445), 1.5: (200, 1294), 2.0: (200, 6076), 2.5: (200, 35242), 3.0: (200, 162847), 3.5: (200, 920196)}, 1,
+     ["--algo", "bp", "--N", "1024", "--K", "512", "--bp-iters", "100"], "1.0:3.5:0.5", 2000, 1 << 16),
 ]
 
 
 def published(key, L):
     pts = {}
+    if isinstance(key, dict):
+        return dict(key)
     for b in PUB[key]:
         if b["L"] != L:
             continue
@@ -36,7 +43,7 @@ def published(key, L):
 
 for title, key, L, args, snr, ble, batch in CURVES:
     t0 = time.time()
-    out = subprocess.run([SIM] + args + ["--fast", "--snr", snr, "--ble", str(ble), "--batch", str(batch), "--seed", "20261004"],
+    out = subprocess.run([SIM] + args + ["--fast", "--snr-list" if "," in snr else "--snr", snr, "--ble", str(ble), "--batch", str(batch), "--seed", "20261004"],
                          capture_output=True, text=True, timeout=1500)
     dt = time.time() - t0
     if out.returncode:
