@@ -26,7 +26,8 @@ extern "C" {
 int polar_testing_select_kernel(polar_ctx *ctx, int variant);
 
 /* k_scl_big: LLR levels <= TL and partial-sum levels <= TB in LDS, written as the two digits TL TB:
- * 35, 46 or 57; 0 = the measured best for the arithmetic type. */
+ * 35, 46 or 57; 351 = 35 with LLR level 4 in the registers of the path's own lanes (L = 32 only; elsewhere it means 35);
+ * 0 = the measured best for the arithmetic type and list size. */
 int polar_testing_big_split(polar_ctx *ctx, int split);
 
 /* The kernels' scalar arithmetic on caller-chosen operands, one thread per element, through the SAME device

@@ -196,11 +196,11 @@ int launch_scl_v(polar_ctx *c, const polar::SclParams &P)
 }
 
 // big lists / long codes: low LLR levels in LDS, the rest in a per-wave scratch slice (scl_big.h)
-template <typename R, typename IN, int LOGL, int TL, int TB>
+template <typename R, typename IN, int LOGL, int TL, int TB, int RL = 0>
 int launch_big_v(polar_ctx *c, const polar::SclParams &P)
 {
-    using Cfg = polar::BigCfg<R, LOGL, TL, TB>;
-    auto kern = polar::k_scl_big<R, IN, LOGL, TL, TB>;
+    using Cfg = polar::BigCfg<R, LOGL, TL, TB, RL>;
+    auto kern = polar::k_scl_big<R, IN, LOGL, TL, TB, RL>;
     const size_t lds = Cfg::lds_bytes;
     const int threads = 64 * Cfg::WAVES;
     HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -254,7 +254,11 @@ static bool sc_lanes_ok(const polar_ctx *c, size_t B)
 template <typename R, typename IN, int LOGL>
 int launch_big(polar_ctx *c, const polar::SclParams &P)
 {
-    const int use = c->big_split ? c->big_split : (sizeof(R) == 8 ? 35 : 46);
+    const int use = c->big_split ? c->big_split : (sizeof(R) == 8 ? (LOGL == 5 ? 351 : 35) : 46);
+    if constexpr (LOGL == 5) {   // L = 32: LLR level TL+1 in registers (third digit of the split code; two such levels, and
+                                 // one above four LDS levels, measured slower: fewer resident wavefronts)
+        if (use == 351) return launch_big_v<R, IN, LOGL, 3, 5, 1>(c, P);
+    }
     if (use == 57) return launch_big_v<R, IN, LOGL, 5, 7>(c, P);
     if (use == 46) return launch_big_v<R, IN, LOGL, 4, 6>(c, P);
     return launch_big_v<R, IN, LOGL, 3, 5>(c, P);
@@ -1303,7 +1307,8 @@ int polar_testing_select_kernel(polar_ctx *c, int variant)
 
 int polar_testing_big_split(polar_ctx *c, int split)
 {
-    if (!c || (split != 0 && split != 35 && split != 46 && split != 57)) return POLAR_EINVAL;
+    if (!c || (split != 0 && split != 35 && split != 46 && split != 57 && split != 351))
+        return POLAR_EINVAL;
     c->big_split = split;
     return POLAR_OK;
 }

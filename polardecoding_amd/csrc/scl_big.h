@@ -32,13 +32,15 @@ namespace polar {
 
 __device__ __forceinline__ uint32_t ld_bypass(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <typename R, int LOGL, int TLv, int TBv>
+template <typename R, int LOGL, int TLv, int TBv, int RLv = 0>
 struct BigCfg {
     static constexpr int L = 1 << LOGL;
     static constexpr int S = 64 / L;
     static constexpr int WAVES = 4;                   // codewords per workgroup; they share only the look-up tables
     static constexpr int TL = TLv;                    // highest LLR level kept in LDS (3..5)
     static constexpr int TB = TBv;                    // highest partial-sum level kept in LDS (5..7)
+    static constexpr int RL = RLv;                    // LLR levels TL+1 .. TL+RL: registers of the path's own lanes (0..2)
+    static_assert(RL >= 0 && RL <= 2 && TLv + RLv <= TBv && (RLv == 0 || (2 << TLv) >= 2 * S), "register levels");
     static constexpr int LOW = (2 << TL) + 1;         // row stride of lowA: odd, so that the paths fall into different banks
     static constexpr int WLU = 1 << (TB - 4);         // partial-sum words per path in LDS
     static constexpr int WL = WLU + 1;                // their row stride (odd)
@@ -59,6 +61,37 @@ struct BigCfg {
 __device__ __forceinline__ int metric_key_i(double x) { return __double2hiint(x); }
 __device__ __forceinline__ int metric_key_i(float x) { return __float_as_int(x); }
 typedef int i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t big_sign(double x) { return (uint32_t)__double2hiint(x) >> 31; }
+__device__ __forceinline__ uint32_t big_sign(float x) { return (uint32_t)__float_as_int(x) >> 31; }
+template <int CTRL>
+__device__ __forceinline__ int big_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+
+// "Every path keeps the branch its lambda favours": kf / ko = 32-bit key of the path's metric with the favoured / the other
+// branch (the same value in all S lanes of a path).  True iff the largest favoured key of the wave is below the smallest other
+// key: then the L favoured candidates are the L smallest of the 2L, all strictly below the median of SCL_1024.c:619-633, no
+// path forks and none dies -- the ranking, its key exchange through LDS and the fork bookkeeping can be skipped.
+template <int S>
+__device__ __forceinline__ bool big_trivial_prune(int kf, int ko)
+{
+    int mx = kf, mn = ko;
+    if constexpr (S < 2) { mx = max(mx, big_dpp<0x121>(mx)); mn = min(mn, big_dpp<0x121>(mn)); }   // row_ror:1
+    if constexpr (S < 4) { mx = max(mx, big_dpp<0x122>(mx)); mn = min(mn, big_dpp<0x122>(mn)); }
+    if constexpr (S < 8) { mx = max(mx, big_dpp<0x124>(mx)); mn = min(mn, big_dpp<0x124>(mn)); }
+    if constexpr (S < 16) { mx = max(mx, big_dpp<0x128>(mx)); mn = min(mn, big_dpp<0x128>(mn)); }
+    if constexpr (S < 32) {
+        auto a = __builtin_amdgcn_permlane16_swap((uint32_t)mx, (uint32_t)mx, false, false);
+        auto b = __builtin_amdgcn_permlane16_swap((uint32_t)mn, (uint32_t)mn, false, false);
+        mx = max((int)a[0], (int)a[1]);
+        mn = min((int)b[0], (int)b[1]);
+    }
+    {
+        auto a = __builtin_amdgcn_permlane32_swap((uint32_t)mx, (uint32_t)mx, false, false);
+        auto b = __builtin_amdgcn_permlane32_swap((uint32_t)mn, (uint32_t)mn, false, false);
+        mx = max((int)a[0], (int)a[1]);
+        mn = min((int)b[0], (int)b[1]);
+    }
+    return __builtin_amdgcn_readfirstlane(mx) < __builtin_amdgcn_readfirstlane(mn);
+}
 
 // everything a wave wrote (LDS and scratch) is visible to its own later loads; no other wave ever reads it
 __device__ __forceinline__ void wave_sync() { __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
@@ -68,17 +101,27 @@ __device__ __forceinline__ void wave_sync() { __asm__ volatile("s_waitcnt vmcnt(
 #else
 #define BIG_STAMP(i) do { } while (0)
 #endif
+#ifdef POLAR_MARKS  // static instruction accounting (tools/count_marks.py): comments in the ISA
+#define BIG_MARK(name) __asm__ volatile("; MARK " name)
+#else
+#define BIG_MARK(name) do { } while (0)
+#endif
 
-template <typename R, typename IN, int LOGL, int TLv, int TBv>
-__global__ __launch_bounds__(256) void k_scl_big(SclParams P)
+// One register level (RL = 1) is worth it only at four wavefronts per SIMD (128 VGPRs): the decoder is a chain of dependent
+// round trips and its rate follows the number of resident wavefronts.
+template <typename R, typename IN, int LOGL, int TLv, int TBv, int RLv = 0>
+__global__ __launch_bounds__(256, RLv == 1 ? 4 : 1) void k_scl_big(SclParams P)
 {
 #ifdef POLAR_STAMPS
     unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
-    using Cfg = BigCfg<R, LOGL, TLv, TBv>;
+    using Cfg = BigCfg<R, LOGL, TLv, TBv, RLv>;
     using State = typename Cfg::State;
-    constexpr int L = Cfg::L, S = Cfg::S, LOW = Cfg::LOW, WL = Cfg::WL, TL = Cfg::TL, TB = Cfg::TB, WAVES = Cfg::WAVES;
+    constexpr int L = Cfg::L, S = Cfg::S, LOW = Cfg::LOW, WL = Cfg::WL, TL = Cfg::TL, TB = Cfg::TB, WAVES = Cfg::WAVES, RL = Cfg::RL;
+    constexpr int TR = TL + RL;                         // highest level that is not in the scratch slice
+    constexpr int PER1 = (RL >= 1) ? (2 << TL) / S : 1; // register level TL+1: element pos + S*k of the path in ra[k]
+    constexpr int PER2 = (RL >= 2) ? (4 << TL) / S : 1; // register level TL+2: rb[k]
     static_assert(S >= 2, "one candidate per lane needs 2L <= 64");
     const int N = P.N, n = P.n, NW = N >> 5;
     const int lane = threadIdx.x & 63;
@@ -119,6 +162,8 @@ __global__ __launch_bounds__(256) void k_scl_big(SclParams P)
         wave_sync();
 
         R PM = R(0);
+        R ra[PER1], rb[PER2];   // register levels (RL > 0); a row belongs to the slot whose lanes hold it, like a row of hiA
+        (void)ra; (void)rb;
         uint64_t ptrA = 0, ptrB = 0;
         uint32_t crc = 0, bl0 = 0, cur0 = 0, fl = 0, fw = 0, ctv = 0;
         int act = 1;
@@ -198,6 +243,77 @@ __global__ __launch_bounds__(256) void k_scl_big(SclParams P)
             wave_sync();
             BIG_STAMP((t >= 6) ? 1 : 2);
         };
+        // ---- level t in (TL, TL+RL]: the path's own S lanes, rows in registers (ra: level TL+1, rb: level TL+2) ----
+        // No leader sharing here (every path evaluates its own row: VALU work instead of a scratch round trip per step).
+        auto reg_c = [&](auto TC, auto GC) {
+            constexpr int t = decltype(TC)::value, h = 1 << t;
+            constexpr bool gstep = decltype(GC)::value;
+            constexpr int PER = h / S;                       // elements per lane: e = pos + S*k
+            static_assert(t > TL && t <= TR && PER >= 1, "register level");
+            auto put = [&](int k, R v) {
+                if constexpr (t == TL + 1) ra[k] = v;
+                else rb[k] = v;
+            };
+            if (p < act) {
+                const int ss = (t + 1 == n) ? 0 : ptr_get<LOGL>(ptrA, t + 1);
+                uint32_t w0 = 0, w1 = 0;                     // partial-sum bits h + e of the path (g step)
+                if (gstep) {
+                    if constexpr (t < 5) w0 = bl0 >> h;
+                    else {
+                        const int bs = ptr_get<LOGL>(ptrB, t);
+                        w0 = blw[bs * WL + (h >> 5)];
+                        if constexpr (t == 6) w1 = blw[bs * WL + (h >> 5) + 1];
+                    }
+                }
+                auto bit_of = [&](int e) -> uint32_t { return (((t == 6 && e >= 32) ? w1 : w0) >> (e & 31)) & 1u; };
+                if constexpr (t < TR) {
+                    // source level t+1 is rb, in the lanes of slot ss
+                    const int sl = ss * S + pos;
+#pragma unroll
+                    for (int k = 0; k < PER; ++k) {
+                        R a = rb[k], b = rb[k + PER];
+                        if (gstep) {
+                            a = __shfl(a, sl);
+                            b = __shfl(b, sl);
+                        }
+                        put(k, gstep ? gfun<R>(a, b, bit_of(pos + k * S)) : chk_lut<R>(a, b, lut));
+                    }
+                } else {
+                    // source level t+1 is a scratch row (written by bulk, drained by its wave_sync), or the channel row
+                    const R *src = (t + 1 == n) ? chg : hiA + (size_t)ss * N + 2 * h;
+                    constexpr int U = PER < 8 ? PER : 8;     // pairs of loads in flight per lane
+#pragma unroll
+                    for (int k0 = 0; k0 < PER; k0 += U) {
+                        R a[U], b[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            a[u] = ld_bypass(src + pos + (k0 + u) * S);
+                            b[u] = ld_bypass(src + pos + (k0 + u) * S + h);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            put(k0 + u, gstep ? gfun<R>(a[u], b[u], bit_of(pos + (k0 + u) * S)) : chk_lut<R>(a[u], b[u], lut));
+                    }
+                }
+                ptrA = ptr_set<LOGL>(ptrA, t, p);
+            }
+        };
+        auto reg = [&](int t, bool gstep) {
+            using std::integral_constant;
+            if constexpr (RL >= 1) {
+                if (t == TL + 1) {
+                    if (gstep) reg_c(integral_constant<int, TL + 1>{}, integral_constant<bool, true>{});
+                    else reg_c(integral_constant<int, TL + 1>{}, integral_constant<bool, false>{});
+                }
+            }
+            if constexpr (RL >= 2) {
+                if (t == TL + 2) {
+                    if (gstep) reg_c(integral_constant<int, TL + 2>{}, integral_constant<bool, true>{});
+                    else reg_c(integral_constant<int, TL + 2>{}, integral_constant<bool, false>{});
+                }
+            }
+            BIG_STAMP(2);
+        };
         // ---- level t <= TL from level t+1 by the path's own lanes ----
         auto low_c = [&](auto TC, auto GC) {
             constexpr int t = decltype(TC)::value, h = 1 << t;
@@ -208,7 +324,23 @@ __global__ __launch_bounds__(256) void k_scl_big(SclParams P)
                 uint32_t wv = 0;
                 if constexpr (t < 5) wv = bl0 >> h;  // bit 2^t + e of the register word
                 else if (gstep) wv = blw[ptr_get<LOGL>(ptrB, 5) * WL + 1];
-                if (t == TL) {
+                if constexpr (t == TL && RL >= 1) {
+                    // level TL+1 is in the registers of slot ss: an f step follows the step that wrote the path's own row
+                    // (ss == p, no exchange), a g step fetches the owner's lanes (SCL_1024.c:404-421 through the pointer)
+                    constexpr int PER = h / S;
+                    static_assert(PER >= 1 && 2 * PER == PER1, "register level above the LDS levels");
+                    const int sl = ss * S + pos;
+#pragma unroll
+                    for (int k = 0; k < PER; ++k) {
+                        const int e = pos + k * S;
+                        R a = ra[k], b = ra[k + PER];
+                        if (gstep) {
+                            a = __shfl(a, sl);
+                            b = __shfl(b, sl);
+                        }
+                        out[e] = gstep ? gfun<R>(a, b, (wv >> e) & 1) : chk_lut<R>(a, b, lut);
+                    }
+                } else if (t == TL) {
                     const R *src = hiA + (size_t)ss * N + 2 * h;
                     constexpr int PER = h / S;                             // elements per lane
                     constexpr int U = PER < 1 ? 1 : (PER < 8 ? PER : 8);   // loads in flight per lane
@@ -260,19 +392,23 @@ __global__ __launch_bounds__(256) void k_scl_big(SclParams P)
                 fw = P.frozen[(j >> 5) + (lane & 1)];            // frozen masks of leaves j..j+31 / j+32..j+63
             }
             // ================= LLR of leaf j for every active path =================
+            BIG_MARK("big_llr");
             int tf = n - 1;
             if (j > 0) {
                 const int d = __builtin_ctz((unsigned)j);
-                if (d > TL) bulk(d, true);
+                if (d > TR) bulk(d, true);
+                else if (d > TL) reg(d, true);
                 else low(d, true);
                 tf = d - 1;
             }
             for (int t = tf; t >= 0; --t) {
-                if (t > TL) bulk(t, false);
+                if (t > TR) bulk(t, false);
+                else if (t > TL) reg(t, false);
                 else low(t, false);
             }
             const R lam = (p < act) ? lowA[p * LOW + 1] : R(0);
             BIG_STAMP(3);
+            BIG_MARK("big_decide");
 
             // ================= decision =================
             const bool frozen = (__builtin_amdgcn_readlane(fw, (j >> 5) & 1) >> (j & 31)) & 1;
@@ -299,9 +435,17 @@ __global__ __launch_bounds__(256) void k_scl_big(SclParams P)
                 act *= 2;
             } else {
                 // phase 2: keep the L best of 2L candidates (SCL_1024.c:610-661)
+                // PHI of the branch lambda favours is T(|lambda|), of the other one T(|lambda|) + |lambda| (:481-502; T + 0
+                // is T), so cb / cw ARE c0 / c1 in the order the sign of lambda says (lambda = +-0: cb == cw, never trivial)
                 const R tt = lut.tabv(lam);
-                const R c0 = PM + (tt + negmax(lam));
-                const R c1 = PM + (tt + posmax(lam));
+                const R cb = PM + tt, cw = PM + (tt + absr(lam));
+                const uint32_t lneg = big_sign(lam);
+                if (big_trivial_prune<S>(metric_key_i(cb), metric_key_i(cw))) {
+                    bit = (int)lneg;
+                    PM = cb;
+                } else {
+                const R c0 = lneg ? cw : cb;
+                const R c1 = lneg ? cb : cw;
                 const R mine = (pos == 0) ? c0 : c1;
                 // First on 32-bit keys (the bits of a float, the high word of a double: monotone for metrics >= 0):
                 // t = key_m - key_own - 1 is negative iff key_m <= key_own, and one v_alignbit shifts that sign bit
@@ -374,10 +518,12 @@ __global__ __launch_bounds__(256) void k_scl_big(SclParams P)
                         PM = c0;
                     }
                 }
+                }
                 __asm__ volatile("" ::: "memory");
             }
 
             BIG_STAMP(frozen ? 4 : 5);
+            BIG_MARK("big_sums");
             // ================= partial sums (updateBit, SCL_1024.c:424-448) =================
             if (bit) crc ^= __builtin_amdgcn_readlane(ctv, j & 63);
             cur0 = (uint32_t)bit;
@@ -441,6 +587,7 @@ __global__ __launch_bounds__(256) void k_scl_big(SclParams P)
                 }
             }
             BIG_STAMP(6);
+            BIG_MARK("big_leaf_end");
         }
 
         // ================= choose the path (SCL_1024.c:667-674; CASCL_1024_L8.c:725-755) =================

@@ -181,6 +181,30 @@ def test_big_list_kernel_list_sizes_vs_oracle(L, dtype, oracle):
         assert np.array_equal(pm, ref_pm)
 
 
+@pytest.mark.parametrize("split", [35, 46, 57, 351])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_big_list_kernel_storage_splits_vs_oracle(split, dtype, oracle):
+    """Every LDS / register / scratch split of k_scl_big (polar_testing_big_split), L = 32: decisions, path metric and
+    flags of the oracle (SCL_1024.c:547-680 with 32 paths), whichever split the library would pick by itself."""
+    import polardecoding_amd as pa
+    from polardecoding_amd import testing as T
+    N, K, L = 1024, 512, 32
+    code = oracle.Code(N, K, pa.CRC24C_TAPS)
+    sim = oracle.Sim(4100 + split)
+    sig = oracle.sigma_from_db(1.0)
+    us, ys = sim.frames(code, sig, 40)
+    llr = np.stack([oracle.llr_from_y(y, sig) for y in ys]).astype(np.float32).astype(np.float64)
+    ref_uh, ref_pm, ref_ties = oracle.decode(code, llr, "CASCL", L=L, dtype=dtype)
+    dec = T.big_split(pa.CASCL(N, K, L=L, dtype=pa.F64 if dtype == "f64" else pa.F32), split)
+    uh, pm, fl = dec.decode_batch(llr)
+    assert np.array_equal(uh, ref_uh)
+    assert np.array_equal((fl & pa.FLAG_TIE) != 0, ref_ties > 0)
+    if dtype == "f64":
+        assert np.array_equal(pm, ref_pm)
+    else:
+        assert np.array_equal(np.asarray(pm, dtype=np.float32), np.asarray(ref_pm, dtype=np.float32))
+
+
 @pytest.mark.parametrize("name", ["SC_1024", "SCL_1024", "CASCL_1024_L8", "CASCL_128", "BP_128"])
 def test_f32_matches_f32_oracle(name, oracle):
     """The f32 kernels keep the operation order: bit-identical to the oracle's f32 instantiation."""
