@@ -73,24 +73,20 @@ __device__ __forceinline__ int big_dpp(int v) { return __builtin_amdgcn_update_d
 template <int S>
 __device__ __forceinline__ bool big_trivial_prune(int kf, int ko)
 {
-    int mx = kf, mn = ko;
-    if constexpr (S < 2) { mx = max(mx, big_dpp<0x121>(mx)); mn = min(mn, big_dpp<0x121>(mn)); }   // row_ror:1
-    if constexpr (S < 4) { mx = max(mx, big_dpp<0x122>(mx)); mn = min(mn, big_dpp<0x122>(mn)); }
-    if constexpr (S < 8) { mx = max(mx, big_dpp<0x124>(mx)); mn = min(mn, big_dpp<0x124>(mn)); }
-    if constexpr (S < 16) { mx = max(mx, big_dpp<0x128>(mx)); mn = min(mn, big_dpp<0x128>(mn)); }
+    int mx = kf;   // the largest favoured key of the wave, then ONE compare per lane: every other key must be above it
+    if constexpr (S < 2) mx = max(mx, big_dpp<0x121>(mx));   // row_ror:1
+    if constexpr (S < 4) mx = max(mx, big_dpp<0x122>(mx));
+    if constexpr (S < 8) mx = max(mx, big_dpp<0x124>(mx));
+    if constexpr (S < 16) mx = max(mx, big_dpp<0x128>(mx));
     if constexpr (S < 32) {
         auto a = __builtin_amdgcn_permlane16_swap((uint32_t)mx, (uint32_t)mx, false, false);
-        auto b = __builtin_amdgcn_permlane16_swap((uint32_t)mn, (uint32_t)mn, false, false);
         mx = max((int)a[0], (int)a[1]);
-        mn = min((int)b[0], (int)b[1]);
     }
     {
         auto a = __builtin_amdgcn_permlane32_swap((uint32_t)mx, (uint32_t)mx, false, false);
-        auto b = __builtin_amdgcn_permlane32_swap((uint32_t)mn, (uint32_t)mn, false, false);
         mx = max((int)a[0], (int)a[1]);
-        mn = min((int)b[0], (int)b[1]);
     }
-    return __builtin_amdgcn_readfirstlane(mx) < __builtin_amdgcn_readfirstlane(mn);
+    return __ballot(mx >= ko) == 0ull;
 }
 
 // everything a wave wrote (LDS and scratch) is visible to its own later loads; no other wave ever reads it

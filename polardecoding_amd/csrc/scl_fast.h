@@ -543,23 +543,19 @@ struct FastDec {
     // true if every path keeps the branch its lambda favours (cb <= cw: its metric with that / the other branch, at pos 0)
     __device__ __forceinline__ bool trivial_prune(R cb, R cw) const
     {
+        // the largest favoured key, then one compare per path: "max favoured < min other" <=> every other key is above it
         const uint32_t m0 = pos == 0 ? 0xFFFFFFFFu : 0u;
-        uint32_t mx = metric_key(cb) & m0, mn = metric_key(cw) | ~m0;
+        uint32_t mx = metric_key(cb) & m0;
         mx = max(mx, (uint32_t)dpp_i<0x128>((int)mx));   // row_ror:8: the other path of this row of 16 lanes
-        mn = min(mn, (uint32_t)dpp_i<0x128>((int)mn));
         {
             auto a = __builtin_amdgcn_permlane16_swap(mx, mx, false, false);
-            auto b = __builtin_amdgcn_permlane16_swap(mn, mn, false, false);
             mx = max(a[0], a[1]);
-            mn = min(b[0], b[1]);
         }
         {
             auto a = __builtin_amdgcn_permlane32_swap(mx, mx, false, false);
-            auto b = __builtin_amdgcn_permlane32_swap(mn, mn, false, false);
             mx = max(a[0], a[1]);
-            mn = min(b[0], b[1]);
         }
-        return __ballot(mx >= mn) == 0ull;
+        return __ballot(mx >= (metric_key(cw) | ~m0)) == 0ull;
     }
 
     // ---- decision at leaf j = 8o + K given lambda (valid at pos 0) ----

@@ -446,23 +446,19 @@ struct Fast2Dec {
     // cb / cw = the path's metric with the favoured / the other branch, cb <= cw, valid at pos 0.
     __device__ __forceinline__ bool trivial_prune(R cb, R cw) const
     {
-        // the other lanes of a path take no part: 0 for the max, ~0 for the min
-        uint32_t mx = metric_key(cb) & pos0_mask, mn = metric_key(cw) | ~pos0_mask;
+        // the largest favoured key of the lane's codeword (the other lanes of a path take no part: 0), then ONE compare per
+        // path: "max favoured < min other" <=> every path's other key is above that maximum
+        uint32_t mx = metric_key(cb) & pos0_mask;
         mx = max(mx, (uint32_t)dpp_i<0x128>((int)mx));   // row_ror:8: the other path of this row of 16 lanes
-        mn = min(mn, (uint32_t)dpp_i<0x128>((int)mn));
         {
             auto a = __builtin_amdgcn_permlane16_swap(mx, mx, false, false);
-            auto b = __builtin_amdgcn_permlane16_swap(mn, mn, false, false);
             mx = max(a[0], a[1]);
-            mn = min(b[0], b[1]);
         }
         {
             auto a = __builtin_amdgcn_permlane32_swap(mx, mx, false, false);
-            auto b = __builtin_amdgcn_permlane32_swap(mn, mn, false, false);
             mx = max(a[0], a[1]);
-            mn = min(b[0], b[1]);
         }
-        return __ballot(mx >= mn) == 0ull;
+        return __ballot(mx >= (metric_key(cw) | ~pos0_mask)) == 0ull;
     }
     static __device__ __forceinline__ uint32_t sign_bit(double x) { return (uint32_t)__double2hiint(x) >> 31; }
     static __device__ __forceinline__ uint32_t sign_bit(float x) { return (uint32_t)__float_as_int(x) >> 31; }

@@ -452,22 +452,17 @@ struct Fast4Dec {
     // true if every path of all four codewords keeps the branch its lambda favours (see k_scl_fast2's decide)
     __device__ __forceinline__ bool trivial_prune(R cb, R cw) const
     {
-        uint32_t mx = metric_key(cb) & pos0_mask, mn = metric_key(cw) | ~pos0_mask;
+        uint32_t mx = metric_key(cb) & pos0_mask;
         mx = max(mx, (uint32_t)dpp_i<0x128>((int)mx));   // row_ror:8: the other path of this row of 16 lanes
-        mn = min(mn, (uint32_t)dpp_i<0x128>((int)mn));
         {
             auto a = __builtin_amdgcn_permlane16_swap(mx, mx, false, false);
-            auto b = __builtin_amdgcn_permlane16_swap(mn, mn, false, false);
             mx = max(a[0], a[1]);
-            mn = min(b[0], b[1]);
         }
         {
             auto a = __builtin_amdgcn_permlane32_swap(mx, mx, false, false);
-            auto b = __builtin_amdgcn_permlane32_swap(mn, mn, false, false);
             mx = max(a[0], a[1]);
-            mn = min(b[0], b[1]);
         }
-        return __ballot(mx >= mn) == 0ull;
+        return __ballot(mx >= (metric_key(cw) | ~pos0_mask)) == 0ull;   // one compare per path instead of a min reduction
     }
     static __device__ __forceinline__ uint32_t sign_bit(double x) { return (uint32_t)__double2hiint(x) >> 31; }
     static __device__ __forceinline__ uint32_t sign_bit(float x) { return (uint32_t)__float_as_int(x) >> 31; }
