@@ -49,6 +49,29 @@ def host_cpu_model():
     return "unknown CPU"
 
 
+def fer_vs_snr(dec, frames):
+    """The second half of BASELINE.json's metric ("... + FER@Eb/N0 sweep"): `frames` frames per point through the
+    device-side transmit chain + decoder + compare (polar_fer_batch), outside the timed region, next to the BLER the
+    reference's own logs hold for this configuration (myResult_1024/CASCL_L8.dat: block errors / run, all seeds)."""
+    pub = {}
+    try:
+        with open(os.path.join(REPO, "tests", "golden", "published_runs.json")) as f:
+            for block in json.load(f).get("myResult_1024/CASCL_L8.dat", []):
+                for snr, ble, run in block["rows"]:
+                    e, r = pub.get(snr, (0, 0))
+                    pub[snr] = (e + ble, r + run)
+    except (OSError, ValueError, KeyError):
+        pub = {}
+    rows = []
+    for snr in (1.0, 1.5, 2.0, 2.5, 3.0):
+        blk, bits = dec.fer_batch(1242, 0, snr, frames)
+        row = {"snr_db": snr, "frames": frames, "block_errors": blk, "fer": blk / float(frames)}
+        if snr in pub:
+            row["published_bler"] = pub[snr][0] / float(pub[snr][1])
+        rows.append(row)
+    return rows
+
+
 def cpu_baseline(snr_db, seconds_target=15.0):
     """The reference's CASCL() itself (oracle/_ref/libCASCL_1024_L8.so, built from /root/reference by
     oracle/Makefile), one thread, decode call only, on frames of the same distribution."""
@@ -95,6 +118,7 @@ def parse_args(argv=None):
     ap.add_argument("--snr", type=float, default=2.0)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fer-sweep", action="store_true", help="skip the FER-vs-Eb/N0 points (outside the timed region)")
     ap.add_argument("--one-stream", action="store_true", help="all steps on one stream (no overlap of consecutive launches)")
     ap.add_argument("--streams", type=int, default=2, help="contexts / HIP streams the steps alternate over")
     ap.add_argument("--rehearse-cpu", action="store_true",
@@ -246,6 +270,10 @@ def run(args):
         except Exception as e:  # pragma: no cover
             secondary = {"error": str(e)}
 
+    fer_sweep = None
+    if rank == 0 and not args.no_fer_sweep:
+        fer_sweep = fer_vs_snr(dec, B)
+
     if rank == 0:
         total_frames = world * B * args.steps
         value = total_frames / elapsed
@@ -278,6 +306,8 @@ def run(args):
                                  "launch alone on its stream; with two streams consecutive steps overlap their partly "
                                  "filled last pass, so ms_per_step can be below kernel_ms"},
         }
+        if fer_sweep:
+            out["fer_sweep"] = fer_sweep
         if secondary:
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
