@@ -40,6 +40,7 @@ int polar_testing_big_split(polar_ctx *ctx, int split);
  *   op 5  phi_lut(a, u = (b != 0))  the form the list kernels inline: tabv(a) + max(+-a, 0)
  *   op 6  chk_cnt(a, b)    staircase counted on the VALU from the signs of |x| - threshold
  *   op 7  chk_idx(a, b)    prefix popcount over 26 cells + one threshold read (the BP kernel)
+ *   op 8  chk_tab(a, b)    the same with the prefix count read from a byte table (measured alternative, not used)
  * is_f32 = 0: a, b, out are double[n]; 1: float[n].  Host pointers. */
 int polar_testing_math(int op, int is_f32, const void *a, const void *b, void *out, size_t n, int device);
 

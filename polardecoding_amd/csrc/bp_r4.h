@@ -26,12 +26,16 @@ namespace polar {
 
 // CHK form: 0 = chk_idx (prefix popcount + one conflict-free threshold read per look-up, 24 bytes of LDS per CHK),
 // 1 = chk_lut (50-cell table, 40 bytes per CHK from scattered cells), 2 = chk_lut1 (one round trip, 56 bytes),
-// 3 = chk_cnt (staircase counted with 14 subtractions, 8 bytes).  With the messages out of LDS the table reads of form 1
+// 3 = chk_cnt (staircase counted with 14 subtractions, 8 bytes), 4 = chk_tab (the prefix count of form 0 read from a 26-byte
+// table: three VALU instructions less per look-up, one more LDS read in the dependent chain -- 0.92 M against 1.19 M: slower).  With the messages out of LDS the table reads of form 1
 // kept the LDS pipe 68 % busy at 42 % VALU (0.90 M frames/s f64); form 3 is VALU-bound by its f64 subtractions (0.85 M).
 // Measured (2^16 frames, 50 iterations): f64 form 0 1.04 M frames/s, form 1 0.89 M; f32 form 0 1.57 M, form 1 1.81 M
 // (a float entry of the 50-cell table is half the bytes) -> -1 picks form 0 for double and form 1 for float.
 #ifndef POLAR_BPR4_CHK
 #define POLAR_BPR4_CHK -1
+#endif
+#ifndef POLAR_BPR4_ABS_LDS
+#define POLAR_BPR4_ABS_LDS 0
 #endif
 
 template <typename R>
@@ -78,6 +82,8 @@ struct BpR4 {
         return chk_lut<R>(a, b, lut);
 #elif POLAR_BPR4_CHK == 3
         return chk_cnt<R>(a, b, dn);
+#elif POLAR_BPR4_CHK == 4
+        return chk_tab<R>(a, b, st);
 #else
         return chk_idx<R>(a, b, st);
 #endif
@@ -184,7 +190,15 @@ __global__ __launch_bounds__(256, (BpR4Cfg<R>::MIN_BLOCKS)) void k_bp_r4(BpParam
     build_delta_by_count<R>(reinterpret_cast<R *>(smem + C::off_dn), threadIdx.x, blockDim.x);
     s.dn = reinterpret_cast<const R *>(smem + C::off_dn);
     Stair<R>::build(smem + C::off_st, threadIdx.x, blockDim.x);
+#if POLAR_BPR4_ABS_LDS
+    {   // The kernel has no static LDS, so its dynamic LDS starts at address 0 (checked by the launcher): binding the staircase
+        // tables by absolute address lets every table read take its offset as an immediate instead of an address add.
+        typedef __attribute__((address_space(3))) unsigned char lds_u8;
+        s.st.bind((const unsigned char *)(lds_u8 *)(uintptr_t)C::off_st);
+    }
+#else
     s.st.bind(smem + C::off_st);
+#endif
     {
         const int e = 4 * s.t;
         s.fz = (P.frozen[e >> 5] >> (e & 31)) & 0xFu;

@@ -1315,7 +1315,7 @@ int polar_testing_big_split(polar_ctx *c, int split)
 
 int polar_testing_math(int op, int is_f32, const void *a, const void *b, void *out, size_t n, int device)
 {
-    if (op < 0 || op > polar::PROBE_CHK_IDX || !a || !b || !out) return POLAR_EINVAL;
+    if (op < 0 || op > polar::PROBE_CHK_TAB || !a || !b || !out) return POLAR_EINVAL;
     if (n == 0) return POLAR_OK;
     DeviceGuard guard(device);
     const size_t es = is_f32 ? 4 : 8;

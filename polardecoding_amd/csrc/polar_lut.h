@@ -249,10 +249,11 @@ struct Cell4<float> {
 
 template <typename R>
 struct Stair {
-    static constexpr size_t bytes = sizeof(R) * (8 + 64);
+    static constexpr size_t bytes = sizeof(R) * (8 + 64) + 32;
     const R *thr;    // LDS [8]: the seven thresholds, then +inf
     const R *dlt;    // LDS [64]: dlt[i * 8 + j] = T_i - T_j
     uint32_t mask;   // bit c set: cell c holds a threshold
+    const unsigned char *pfx;   // LDS [26] bytes, by cell: the number of thresholds in the cells below
 
     static __device__ __forceinline__ int cell_of(R x)
     {
@@ -266,11 +267,18 @@ struct Stair {
         const R tv[8] = {R(0.65), R(0.55), R(0.45), R(0.35), R(0.25), R(0.15), R(0.05), R(0)};
         for (int i = tid; i < 8; i += nthreads) t[i] = thr7[i];
         for (int i = tid; i < 64; i += nthreads) t[8 + i] = tv[i >> 3] - tv[i & 7];
+        unsigned char *pf = reinterpret_cast<unsigned char *>(t + 72);
+        for (int c = tid; c < 32; c += nthreads) {
+            int nb = 0;
+            for (int k = 0; k < 7; ++k) nb += (cell_of(thr7[k]) < c) ? 1 : 0;
+            pf[c] = (unsigned char)nb;
+        }
     }
     __device__ __forceinline__ void bind(const unsigned char *mem)
     {
         thr = reinterpret_cast<const R *>(mem);
         dlt = thr + 8;
+        pfx = reinterpret_cast<const unsigned char *>(dlt + 64);
         const R thr7[7] = {R(0.196), R(0.433), R(0.71), R(1.05), R(1.508), R(2.252), R(4.5)};
         mask = 0;
 #pragma unroll
@@ -283,12 +291,28 @@ struct Stair {
         const uint32_t b = (uint32_t)__popc(mask & ((1u << c) - 1u));
         return b + ((absr(x) >= thr[b]) ? 1u : 0u);
     }
+    // the same with the prefix count read from a 26-byte table instead of mask / shift / popcount: three VALU instructions
+    // less per look-up for one more (conflict-free: seven consecutive words) LDS read in the dependent chain
+    __device__ __forceinline__ uint32_t level_tab(R x) const
+    {
+        const int t = min(max(Cell4<R>::raw(x), Cell4<R>::BIAS - 1), Cell4<R>::BIAS + 24);
+        const uint32_t b = pfx[(uint32_t)t - (uint32_t)(Cell4<R>::BIAS - 1)];
+        return b + ((absr(x) >= thr[b]) ? 1u : 0u);
+    }
 };
 
 template <typename R>
 __device__ __forceinline__ R chk_idx(R a, R b, const Stair<R> &S)
 {
     const uint32_t is = S.level(a + b), id = S.level(a - b);
+    const R delta = S.dlt[is * 8 + id];
+    return xor_sign(minabs(a, b), a, b) + delta;
+}
+
+template <typename R>
+__device__ __forceinline__ R chk_tab(R a, R b, const Stair<R> &S)
+{
+    const uint32_t is = S.level_tab(a + b), id = S.level_tab(a - b);
     const R delta = S.dlt[is * 8 + id];
     return xor_sign(minabs(a, b), a, b) + delta;
 }

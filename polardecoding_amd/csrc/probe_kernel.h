@@ -7,7 +7,7 @@
 
 namespace polar {
 
-enum { PROBE_CHK = 0, PROBE_CHK_LUT = 1, PROBE_CHK_LUT1 = 2, PROBE_TABV = 3, PROBE_PHI = 4, PROBE_PHI_LUT = 5, PROBE_CHK_CNT = 6, PROBE_CHK_IDX = 7 };
+enum { PROBE_CHK = 0, PROBE_CHK_LUT = 1, PROBE_CHK_LUT1 = 2, PROBE_TABV = 3, PROBE_PHI = 4, PROBE_PHI_LUT = 5, PROBE_CHK_CNT = 6, PROBE_CHK_IDX = 7, PROBE_CHK_TAB = 8 };
 
 // the metric increment exactly as the list kernels write it (scl_fast2.h decide, scl_big.h, scl_generic.h)
 template <typename R>
@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(256) k_probe_math(int op, const R *a, const R 
         case PROBE_PHI: r = phi<R>(x, y != R(0) ? 1 : 0); break;
         case PROBE_CHK_CNT: r = chk_cnt<R>(x, y, dn); break;
         case PROBE_CHK_IDX: r = chk_idx<R>(x, y, st); break;
+        case PROBE_CHK_TAB: r = chk_tab<R>(x, y, st); break;
         default: r = phi_lut<R>(x, y != R(0) ? 1 : 0, lut); break;
         }
         out[i] = r;

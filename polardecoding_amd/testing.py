@@ -7,7 +7,7 @@ import numpy as np
 from .api import PolarError, load_library
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_GENERIC_SPILL, KERNEL_BIG, KERNEL_ONE_PER_WAVE, KERNEL_FOUR_PER_WAVE = 0, 1, 2, 3, 4, 5
-OP_CHK, OP_CHK_LUT, OP_CHK_LUT1, OP_TABV, OP_PHI, OP_PHI_LUT, OP_CHK_CNT, OP_CHK_IDX = 0, 1, 2, 3, 4, 5, 6, 7
+OP_CHK, OP_CHK_LUT, OP_CHK_LUT1, OP_TABV, OP_PHI, OP_PHI_LUT, OP_CHK_CNT, OP_CHK_IDX, OP_CHK_TAB = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 
 def select_kernel(dec, variant):

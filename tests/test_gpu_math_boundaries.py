@@ -80,7 +80,7 @@ def test_check_node_forms_bit_identical_to_oracle(dtype, oracle):
     assert a.size > 800000
     ref = oracle.math(0, a, b, dtype)
     assert np.isfinite(ref).all()
-    for op in (T.OP_CHK, T.OP_CHK_LUT, T.OP_CHK_LUT1, T.OP_CHK_CNT, T.OP_CHK_IDX):
+    for op in (T.OP_CHK, T.OP_CHK_LUT, T.OP_CHK_LUT1, T.OP_CHK_CNT, T.OP_CHK_IDX, T.OP_CHK_TAB):
         got = T.math(op, a, b, dtype)
         # -0.0 + (+0.0): the sign of a zero result is the only place the forms may legitimately be compared by value
         # -- they are not allowed to differ there either
