@@ -54,6 +54,20 @@ static int ref_printf(const char *fmt, ...)
     va_start(ap, fmt);
     rv = vprintf(fmt, ap);
     va_end(ap);
+#ifdef REF_BUILD_EXE
+    {   /* test harness only: REF_STOP_AFTER_LINES=k ends the program (cleanly, between two frames) once main() has printed k
+         * lines -- the tail of a sweep can be hundreds of thousands of frames that a test does not need */
+        static long lines = 0, limit = -1;
+        if (limit < 0) {
+            const char *e = getenv("REF_STOP_AFTER_LINES");
+            limit = e ? atol(e) : 0;
+        }
+        if (strchr(fmt, '\n') && limit > 0 && ++lines >= limit) {
+            fflush(stdout);
+            exit(0);
+        }
+    }
+#endif
     return rv;
 }
 #ifdef REF_DROPIN

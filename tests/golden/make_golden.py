@@ -15,6 +15,9 @@ stores inputs + outputs:
 
 BPr_128_main_seed7.txt is the first 43 lines (three Eb/N0 points) of `oracle/_ref/BPr_128_main 7`, the compiled
 BPr_128.c main() with its time() seed pinned to 7 (4 minutes of CPU for all seven points).
+BP_128_main_seed7.txt is everything `oracle/_ref/BP_128_main 7` prints (BP_128.c's main(), 100 iterations, 200 block
+errors per point, 1.0 .. 4.0 dB: 144 640 frames, 4.5 minutes of CPU) -- what tests/test_gpu_dropin.py expects from the
+same main() with its decode call bound to the library.
 
 ties_<name>.npz (SCL_128, CASCL_128, SCL_1024, CASCL_1024_L8): frames on which the list decoders meet a MEDIAN TIE
 (SCL_1024.c:619-633), which AWGN inputs in double precision practically never produce: observations on a grid of
@@ -119,6 +122,17 @@ TIE_PROGRAMS = {"SCL_128": (16, 3, 8, 4), "CASCL_128": (16, 3, 8, 4), "SCL_1024"
                 "CASCL_1024_L8": (6, 2, 4, 2)}   # frames wanted: tie, never-returns, near-tie, clean
 TIE_GRID = 64.0
 TIE_SIGMA = 0.5
+
+
+def make_main_outputs():
+    """stdout of unmodified reference programs with the seed pinned (text the programs printed: data, not source)."""
+    import subprocess
+    for exe, seed, fname in (("BP_128_main", 7, "BP_128_main_seed7.txt"),):
+        out = subprocess.run([os.path.join(REPO, "oracle", "_ref", exe), str(seed)], capture_output=True, text=True,
+                             timeout=3600, check=True).stdout
+        with open(os.path.join(HERE, fname), "w") as f:
+            f.write(out)
+        print(fname, len(out.splitlines()), "lines")
 
 
 def _probe_returns(name, y, limit=20.0):
@@ -259,5 +273,7 @@ if __name__ == "__main__":
     make_ties(only)
     if not only or "BPr_128" in only:
         make_bpr()
+    if not only or "mains" in only:
+        make_main_outputs()
     if not only:
         make_published()

@@ -52,3 +52,45 @@ def test_sc_128_main_with_the_library_prints_the_published_log():
     with open(os.path.join(GOLDEN, "published_runs.json")) as f:
         pub = json.load(f)["myResult_128/SC128out.txt"][0]
     assert [int(x) for x in re.findall(r"run = (\d+)", mine)] == [r[2] for r in pub["rows"]]
+
+
+def _first_lines(exe, seed, nlines, timeout=600):
+    """stdout of exe up to its first nlines lines: the wrapper around the reference's main() (oracle/ref_wrap.c) leaves the
+    program after that many printed lines when REF_STOP_AFTER_LINES is set -- the rest of the sweep is not needed"""
+    path = os.path.join(REF, exe)
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not built (make -C oracle ref dropin, needs /root/reference)")
+    out = subprocess.run([path, str(seed)], capture_output=True, text=True, timeout=timeout,
+                         env=dict(os.environ, REF_STOP_AFTER_LINES=str(nlines)))
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout.splitlines(keepends=True)
+
+
+def test_scl_1024_main_with_the_library_prints_the_published_log():
+    """SCL_1024.c as it stands (L = 8, fixed SEED 1024, 50 block errors per point): the first four points, 28 695 frames with
+    one polar_decode() each, are the lines of myResult_1024.zip:SCL1024out.dat (L = 8 block) in the program's own format
+    (SCL_1024.c:277-278); the fifth point (178 842 frames) is left to tests/test_gpu_kat.py, which decodes it in batches."""
+    with open(os.path.join(GOLDEN, "published_runs.json")) as f:
+        pub = [b for b in json.load(f)["myResult_1024/SCL1024out.dat"] if b["L"] == 8][0]
+    want = ["L = 8\tbSNR = %.2f\terror block = %d\trun = %d\tBLER = %fe-2\n" % (snr, eb, run, eb * 100.0 / run)
+            for snr, eb, run in pub["rows"][:4]]
+    assert _first_lines("SCL_1024_dropin_main", 0, 4) == want
+
+
+def test_scl_128_main_with_the_library():
+    """SCL_128.c (L = 8, 1.0 .. 2.5 dB): same stdout as the unmodified program, which is the published log's L = 8 block"""
+    mine = _run("SCL_128_dropin_main", 0)
+    theirs = _run("SCL_128_main", 0)
+    assert mine == theirs
+    with open(os.path.join(GOLDEN, "published_runs.json")) as f:
+        pub = [b for b in json.load(f)["myResult_128/SCL128out_errblock50.dat"] if b["L"] == 8][0]
+    assert [int(x) for x in re.findall(r"run = (\d+)", mine)] == [r[2] for r in pub["rows"][:4]]
+
+
+def test_bp_128_main_with_the_library():
+    """BP_128.c (flooding BP, 100 iterations, 200 block errors per point, 1.0 .. 4.0 dB) with its time() seed pinned to 7:
+    144 640 frames, one polar_decode() each, print what the unmodified program printed (BLER and BER lines; fixture
+    tests/golden/BP_128_main_seed7.txt, made by make_golden.py from oracle/_ref/BP_128_main: 4.5 minutes of CPU)"""
+    mine = _run("BP_128_dropin_main", 7)
+    with open(os.path.join(GOLDEN, "BP_128_main_seed7.txt")) as f:
+        assert mine == f.read()
