@@ -5,10 +5,12 @@
 // There is no cross-lane instruction, no divergence and no idle lane anywhere in the decoder.
 //
 //   LLR levels 0..4 (the 31 lowest values): registers, fully unrolled 32-leaf block (template recursion).
-//   LLR levels 5..n (n = channel): the wavefront's slice of a global scratch buffer, element e of level t at
+//   LLR levels 5..n-1: the wavefront's slice of a global scratch buffer, element e of level t at
 //     (2^t + e)*64 + lane -- every load and store of a level step is one coalesced 512-byte row.
 //     Plain stores, sc1 loads, s_waitcnt vmcnt(0) between a step and its consumer.
-//   Input rows [frame][N] are turned into that layout through a 32 x 64 LDS tile (coalesced on both sides).
+//   Input rows [frame][N] are never copied: the two steps that read the channel level (f at the first block, g at the
+//     middle one) take their operands straight from the caller's rows, lane l from frame l's row, sixteen consecutive
+//     elements (one or half a cache line) per lane and burst, so that every line is fetched once per step.
 //   Partial sums: bits < 32 in a register, levels >= 5 as words [w][lane] in LDS.
 //   Subtrees without an information leaf are skipped altogether: their decisions are 0, their partial sums 0,
 //   and SC (unlike SCL) needs nothing else from them, so every decision and every LLR that IS computed is the
@@ -23,18 +25,13 @@ namespace polar {
 template <typename R>
 struct ScLanesCfg {
     static constexpr int WAVES = 4;
-#ifndef POLAR_SC_TJ
-#define POLAR_SC_TJ 32
-#endif
 #ifndef POLAR_SC_WAVES_PER_SIMD
 #define POLAR_SC_WAVES_PER_SIMD 2
 #endif
-    static constexpr int TJ = POLAR_SC_TJ;                          // tile: TJ elements x 64 frames
-    static constexpr size_t tile_bytes = sizeof(R) * TJ * 65;
     static constexpr size_t bits_bytes(int N) { return 4 * 64 * (size_t)(N / 32 + N / 64); }   // blw[NW][64] + curw[NW/2][64]
-    static constexpr size_t wave_bytes(int N) { return ((tile_bytes > bits_bytes(N) ? tile_bytes : bits_bytes(N)) + 15) & ~(size_t)15; }
+    static constexpr size_t wave_bytes(int N) { return (bits_bytes(N) + 15) & ~(size_t)15; }
     static constexpr size_t lds_bytes(int N) { return wave_bytes(N) * WAVES + Lut<R>::bytes; }
-    static constexpr size_t scratch_bytes(int N) { return sizeof(R) * 2 * (size_t)N * 64; }
+    static constexpr size_t scratch_bytes(int N) { return sizeof(R) * (size_t)N * 64; }   // levels 5 .. n-1: element indices < N
 };
 
 template <typename R>
@@ -83,8 +80,7 @@ __global__ __launch_bounds__(256, POLAR_SC_WAVES_PER_SIMD) void k_sc_lanes(SclPa
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *mine = smem + (size_t)wave * Cfg::wave_bytes(N);
-    R *tile = reinterpret_cast<R *>(mine);                       // [TJ][65] while a batch is loaded
-    uint32_t *blw = reinterpret_cast<uint32_t *>(mine);          // [NW][64] afterwards: saved left partial sums
+    uint32_t *blw = reinterpret_cast<uint32_t *>(mine);          // [NW][64]: saved left partial sums
     uint32_t *curw = blw + (size_t)NW * 64;                      // [NW/2][64] working partial sums
     unsigned char *lut_mem = smem + (size_t)Cfg::WAVES * Cfg::wave_bytes(N);
     Lut<R>::build(lut_mem, threadIdx.x, blockDim.x);
@@ -100,26 +96,28 @@ __global__ __launch_bounds__(256, POLAR_SC_WAVES_PER_SIMD) void k_sc_lanes(SclPa
 
     for (int batch = slot; batch < nbatch; batch += nslots) {
         const int frame0 = batch << 6;
-        // ---- channel LLRs (SC_128.c:416-420), transposed to [element][lane] through the LDS tile ----
-        for (int j0 = 0; j0 < N; j0 += Cfg::TJ) {
-            sync();
-            constexpr int FP = 64 / Cfg::TJ;   // frames per pass
-#pragma unroll 4
-            for (int f = 0; f < 64; f += FP) {
-                const int fr = frame0 + f + lane / Cfg::TJ;
-                double v = 0.0;
-                if (fr < P.B) {
-                    v = (double)reinterpret_cast<const IN *>(P.in)[(size_t)fr * N + j0 + (lane % Cfg::TJ)];
-                    if (P.sigma > 0) v = llr_from_y(v, P.sigma);
-                }
-                tile[(lane % Cfg::TJ) * 65 + f + lane / Cfg::TJ] = (R)v;
+        // ---- channel LLRs (SC_128.c:416-420): read in place, by the two steps at level n-1 ----
+        const bool have = frame0 + lane < P.B;   // the ragged last batch: idle lanes compute on zeros and store nothing
+        const IN *row = reinterpret_cast<const IN *>(P.in) + (size_t)(have ? frame0 + lane : 0) * N;
+        const bool al16 = ((reinterpret_cast<uintptr_t>(P.in) | ((size_t)N * sizeof(IN))) & 15u) == 0;   // uniform
+        auto chan16 = [&](int e0, R *dst) {   // elements e0 .. e0+15 of the lane's row (e0 a multiple of 16)
+            IN raw[16];
+            if (al16) {
+                const IN *r = reinterpret_cast<const IN *>(__builtin_assume_aligned(row + e0, 16));
+#pragma unroll
+                for (int u = 0; u < 16; ++u) raw[u] = r[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) raw[u] = row[e0 + u];
             }
-            sync();
-#pragma unroll 4
-            for (int jj = 0; jj < Cfg::TJ; ++jj) *at(N + j0 + jj) = tile[jj * 65 + lane];
-        }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                double v = have ? (double)raw[u] : 0.0;
+                if (P.sigma > 0) v = llr_from_y(v, P.sigma);
+                dst[u] = (R)v;
+            }
+        };
         sync();
-
         uint32_t fwv = 0;   // lane l: frozen word of block (b & ~63) + l
         for (int b = 0; b < NW; ++b) {
             if ((b & 63) == 0) fwv = (b + lane < NW) ? P.frozen[b + lane] : 0xFFFFFFFFu;
@@ -137,6 +135,16 @@ __global__ __launch_bounds__(256, POLAR_SC_WAVES_PER_SIMD) void k_sc_lanes(SclPa
                 live = !frozen_span(b, 1 << (d - 5));
                 if (live) {
                     const uint32_t *bw = blw + (size_t)(h >> 5) * 64 + lane;   // left partial sums of level d
+                    if (d == n - 1) {   // from the channel rows: 16 consecutive elements per lane and burst
+                        for (int e0 = 0; e0 < h; e0 += 16) {
+                            R a[16], c[16];
+                            const uint32_t wv = bw[(size_t)(e0 >> 5) * 64];
+                            chan16(e0, a);
+                            chan16(e0 + h, c);
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) *at(h + e0 + u) = gfun<R>(a[u], c[u], (wv >> ((e0 + u) & 31)) & 1u);
+                        }
+                    } else
                     for (int e0 = 0; e0 < h; e0 += 8) {
                         R a[8], c[8];
                         const uint32_t wv = bw[(size_t)(e0 >> 5) * 64];
@@ -156,6 +164,15 @@ __global__ __launch_bounds__(256, POLAR_SC_WAVES_PER_SIMD) void k_sc_lanes(SclPa
                 const int h = 1 << t;
                 live = !frozen_span(b, 1 << (t - 5));
                 if (!live) break;
+                if (t == n - 1) {   // from the channel rows
+                    for (int e0 = 0; e0 < h; e0 += 16) {
+                        R a[16], c[16];
+                        chan16(e0, a);
+                        chan16(e0 + h, c);
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) *at(h + e0 + u) = chk_lut<R>(a[u], c[u], lut);
+                    }
+                } else
                 for (int e0 = 0; e0 < h; e0 += 8) {
                     R a[8], c[8];
 #pragma unroll
@@ -174,16 +191,32 @@ __global__ __launch_bounds__(256, POLAR_SC_WAVES_PER_SIMD) void k_sc_lanes(SclPa
             if (live && fz != 0xFFFFFFFFu) {
                 ScLanes<R> S{lut, fz, 0u};
                 uint32_t bl = 0, br = 0;
-                if ((fz & 0xFFFFu) != 0xFFFFu) {
-                    R l[16];
+                // N = 32: level 5 IS the channel level, read in place like the level n-1 steps above
+                auto lvl5 = [&](int e, R *lo, R *hi) {
+                    if (n == 5) {
+                        chan16(0, lo);
+                        chan16(16, hi);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) l[e] = chk_lut<R>(ld_bypass(at(32 + e)), ld_bypass(at(48 + e)), lut);
+                        for (int u = 0; u < 16; ++u) {
+                            lo[u] = ld_bypass(at(32 + u));
+                            hi[u] = ld_bypass(at(48 + u));
+                        }
+                    }
+                    (void)e;
+                };
+                if ((fz & 0xFFFFu) != 0xFFFFu) {
+                    R l[16], lo[16], hi[16];
+                    lvl5(0, lo, hi);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) l[e] = chk_lut<R>(lo[e], hi[e], lut);
                     bl = S.template rec<4, 0>(l);
                 }
                 if ((fz >> 16) != 0xFFFFu) {
-                    R r[16];
+                    R r[16], lo[16], hi[16];
+                    lvl5(0, lo, hi);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) r[e] = gfun<R>(ld_bypass(at(32 + e)), ld_bypass(at(48 + e)), (bl >> e) & 1u);
+                    for (int e = 0; e < 16; ++e) r[e] = gfun<R>(lo[e], hi[e], (bl >> e) & 1u);
                     br = S.template rec<4, 16>(r);
                 }
                 beta = (bl ^ br) | (br << 16);
