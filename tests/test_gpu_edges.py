@@ -143,3 +143,32 @@ def test_two_host_threads_two_contexts(oracle):
     for uh, pm in out:
         assert np.array_equal(uh.reshape(400, 40, 1024), np.broadcast_to(ref, (400, 40, 1024)))
         assert np.array_equal(pm.reshape(400, 40), np.broadcast_to(ref_pm, (400, 40)))
+
+
+@pytest.mark.parametrize("in_dtype", ["f64", "f32"])
+@pytest.mark.parametrize("shift", [0, 1])
+def test_sc_channel_rows_read_in_place_any_alignment(in_dtype, shift, oracle):
+    """k_sc_lanes reads the channel LLRs straight from the caller's device rows (16 elements per lane and burst, 16-byte
+    vector loads when the buffer allows): a buffer that starts one element past a 16-byte boundary must take the scalar
+    path and give the same decisions, for f64 and f32 input rows, with a ragged last batch of 64."""
+    import torch
+    import polardecoding_amd as pa
+    N, K, B = 1024, 512, 64 * 3 + 11
+    code = oracle.Code(N, K)
+    sim = oracle.Sim(90210 + shift)
+    sig = oracle.sigma_from_db(1.5)
+    us, ys = sim.frames(code, sig, B)
+    llr = np.stack([oracle.llr_from_y(y, sig) for y in ys]).astype(np.float32).astype(np.float64)
+    ref_uh, _, _ = oracle.decode(code, llr, "SC")
+    tdt = torch.float64 if in_dtype == "f64" else torch.float32
+    flat = torch.empty(B * N + 4, dtype=tdt, device="cuda")
+    x = flat[shift:shift + B * N].view(B, N)
+    x.copy_(torch.from_numpy(llr).to(tdt))
+    assert x.is_contiguous() and (x.data_ptr() % 16 == 0) == (shift == 0 or (in_dtype == "f32" and shift % 4 == 0))
+    dec = pa.SCdecode(N, K)
+    assert "k_sc_lanes" in dec.kernel_name
+    bits = dec.decode_device(x)
+    dec.synchronize()
+    w = bits.cpu().numpy().view(np.uint32)
+    uh = ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B, N).astype(np.int32)
+    assert np.array_equal(uh, ref_uh)
