@@ -26,7 +26,7 @@ extern "C" {
 int polar_testing_select_kernel(polar_ctx *ctx, int variant);
 
 /* k_scl_big: LLR levels <= TL and partial-sum levels <= TB in LDS, written as the two digits TL TB:
- * 35, 46 or 57; 351 = 35 with LLR level 4 in the registers of the path's own lanes (L = 32 only; elsewhere it means 35);
+ * 35, 46 or 57; 351 / 371 = 35 / 37 with LLR level 4 in the registers of the path's own lanes (L = 32 only; elsewhere 35);
  * 0 = the measured best for the arithmetic type and list size. */
 int polar_testing_big_split(polar_ctx *ctx, int split);
 

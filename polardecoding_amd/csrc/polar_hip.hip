@@ -254,10 +254,13 @@ static bool sc_lanes_ok(const polar_ctx *c, size_t B)
 template <typename R, typename IN, int LOGL>
 int launch_big(polar_ctx *c, const polar::SclParams &P)
 {
-    const int use = c->big_split ? c->big_split : (sizeof(R) == 8 ? (LOGL == 5 ? 351 : 35) : 46);
+    const int use = c->big_split ? c->big_split : (sizeof(R) == 8 ? (LOGL == 5 ? 371 : 35) : 46);
     if constexpr (LOGL == 5) {   // L = 32: LLR level TL+1 in registers (third digit of the split code; two such levels, and
-                                 // one above four LDS levels, measured slower: fewer resident wavefronts)
+                                 // one above four LDS levels, measured slower: fewer resident wavefronts).  At the four
+                                 // wavefronts per SIMD of that kernel the LDS has room for partial-sum levels 6 and 7 too
+                                 // (371: two scratch round trips less per 128 leaves, +3 %)
         if (use == 351) return launch_big_v<R, IN, LOGL, 3, 5, 1>(c, P);
+        if (use == 371) return launch_big_v<R, IN, LOGL, 3, 7, 1>(c, P);
     }
     if (use == 57) return launch_big_v<R, IN, LOGL, 5, 7>(c, P);
     if (use == 46) return launch_big_v<R, IN, LOGL, 4, 6>(c, P);
@@ -1307,7 +1310,7 @@ int polar_testing_select_kernel(polar_ctx *c, int variant)
 
 int polar_testing_big_split(polar_ctx *c, int split)
 {
-    if (!c || (split != 0 && split != 35 && split != 46 && split != 57 && split != 351))
+    if (!c || (split != 0 && split != 35 && split != 46 && split != 57 && split != 351 && split != 371))
         return POLAR_EINVAL;
     c->big_split = split;
     return POLAR_OK;

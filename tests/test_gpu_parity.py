@@ -181,7 +181,7 @@ def test_big_list_kernel_list_sizes_vs_oracle(L, dtype, oracle):
         assert np.array_equal(pm, ref_pm)
 
 
-@pytest.mark.parametrize("split", [35, 46, 57, 351])
+@pytest.mark.parametrize("split", [35, 46, 57, 351, 371])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_big_list_kernel_storage_splits_vs_oracle(split, dtype, oracle):
     """Every LDS / register / scratch split of k_scl_big (polar_testing_big_split), L = 32: decisions, path metric and

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: k_scl_big storage splits side by side (polar_testing_big_split): every split must give the outputs
 and path metrics of the first one bit for bit; prints the kernel-timed rate of each.
-    python tools/big_split_sweep.py --dtype f64 --splits 35,351"""
+    python tools/big_split_sweep.py --dtype f64 --splits 35,351,371"""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,7 @@ from polardecoding_amd import testing as T
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="f64")
-ap.add_argument("--splits", default="35,351,352")
+ap.add_argument("--splits", default="35,351,371")
 ap.add_argument("--only", default="")
 ap.add_argument("--snr", type=float, default=2.0)
 args = ap.parse_args()
