@@ -178,10 +178,17 @@ class Decoder:
                     "polar_decode")
         return uh
 
-    def decode_batch(self, llr, frozen_mask=None, want_pm=True):
+    def decode_batch(self, llr, frozen_mask=None, want_pm=True, out=None):
+        """out: optional int32 [B][N] array to receive u_hat (a caller that keeps its buffers, as the reference does, pays
+        no page faults for a fresh half-gigabyte array per call)."""
         llr = np.ascontiguousarray(llr, dtype=np.float64).reshape(-1, self.N)
         B = llr.shape[0]
-        uh = np.empty((B, self.N), dtype=np.int32)
+        if out is not None:
+            if out.dtype != np.int32 or out.shape != (B, self.N) or not out.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be a C-contiguous int32 array of shape (B, N)")
+            uh = out
+        else:
+            uh = np.empty((B, self.N), dtype=np.int32)
         pm = np.zeros(B, dtype=np.float64)
         fl = np.zeros(B, dtype=np.uint32)
         fm = None

@@ -62,6 +62,8 @@ struct polar_ctx {
     Buf in2[2], bits2[2];                 // chunked host pipeline: ping-pong device buffers
     uint32_t *h_bits[2] = {nullptr, nullptr};   // pinned host copies of the packed decisions
     size_t h_bits_cap = 0;
+    double *h_in[2] = {nullptr, nullptr};       // pinned staging of the caller's (pageable) input chunks, big batches only
+    size_t h_in_cap = 0;
     hipStream_t copy_stream = nullptr;    // host -> device copies overlap the decode of the previous chunk
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     Buf scratch;                          // k_scl_fast per-wave scratch
@@ -571,8 +573,10 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
     if ((rc = ensure(c, c->pm, B * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->flags, B * sizeof(uint32_t)))) return rc;
     // Chunked pipeline: while chunk k is decoded, chunk k+1 crosses PCIe on a second stream and the decisions of
-    // chunk k-1 are unpacked to the caller's int array by helper threads.  The input is pageable caller memory,
-    // so the copy blocks this thread; that is why the unpacking has its own.
+    // chunk k-1 are unpacked to the caller's int array by helper threads.  The input is pageable caller memory: a
+    // hipMemcpyAsync from it is a single-threaded staging copy inside the runtime (about 18 GB/s) that blocks this thread.
+    // Batches of several chunks are therefore staged HERE, by helper threads, into pinned buffers, and cross PCIe as true
+    // asynchronous DMA.
     const size_t CH = 16384;
     const size_t nch = (B + CH - 1) / CH;
     const size_t chf = std::min(B, CH);
@@ -596,6 +600,29 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
             HIP_TRY(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
         }
     }
+    const bool staged = nch >= 3;
+    if (staged && c->h_in_cap < chf * N * sizeof(double)) {
+        for (int i = 0; i < 2; ++i) {
+            if (c->h_in[i]) HIP_TRY(c, hipHostFree(c->h_in[i]));
+            c->h_in[i] = nullptr;
+            HIP_TRY(c, hipHostMalloc((void **)&c->h_in[i], chf * N * sizeof(double), hipHostMallocDefault));
+        }
+        c->h_in_cap = chf * N * sizeof(double);
+    }
+    auto stage_chunk = [&](size_t k) {    // caller's rows of chunk k -> pinned h_in[k & 1], four threads
+        const size_t f0 = k * CH, nf = std::min(CH, B - f0);
+        const double *src = in + f0 * (size_t)N;
+        double *dst = c->h_in[k & 1];
+        const unsigned nthr = 4;
+        auto part = [=](unsigned t) {
+            const size_t a = nf * t / nthr, b = nf * (t + 1) / nthr;
+            std::memcpy(dst + a * (size_t)N, src + a * (size_t)N, (b - a) * (size_t)N * sizeof(double));
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(part, t);
+        part(0);
+        for (auto &th : pool) th.join();
+    };
     std::thread worker;
     auto unpack_chunk = [&](size_t k) {   // decisions of chunk k: pinned words -> caller's int u_hat[][N]
         const size_t f0 = k * CH, nf = std::min(CH, B - f0);
@@ -621,7 +648,14 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
         const size_t f0 = k * CH, nf = std::min(CH, B - f0);
         // the decode of chunk k-2 must be done with in2[s] before it is overwritten
         if (k >= 2 && hipStreamWaitEvent(c->copy_stream, c->ev_free[s], 0) != hipSuccess) return fail_join(POLAR_EDEVICE);
-        if (hipMemcpyAsync(c->in2[s].p, in + f0 * (size_t)N, nf * N * sizeof(double), hipMemcpyHostToDevice,
+        const double *h_src = in + f0 * (size_t)N;
+        if (staged) {
+            // h_in[s] was the source of chunk k-2's DMA: that copy must have left it (ev_in[s] is recorded behind it)
+            if (k >= 2 && hipEventSynchronize(c->ev_in[s]) != hipSuccess) return fail_join(POLAR_EDEVICE);
+            stage_chunk(k);
+            h_src = c->h_in[s];
+        }
+        if (hipMemcpyAsync(c->in2[s].p, h_src, nf * N * sizeof(double), hipMemcpyHostToDevice,
                            c->copy_stream) != hipSuccess) return fail_join(POLAR_EDEVICE);
         if (hipEventRecord(c->ev_in[s], c->copy_stream) != hipSuccess) return fail_join(POLAR_EDEVICE);
         if (hipStreamWaitEvent(c->stream, c->ev_in[s], 0) != hipSuccess) return fail_join(POLAR_EDEVICE);
@@ -792,6 +826,7 @@ void polar_destroy(polar_ctx *c)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 2; ++i) {
         if (c->h_bits[i]) (void)hipHostFree(c->h_bits[i]);
+        if (c->h_in[i]) (void)hipHostFree(c->h_in[i]);
         if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
         if (c->ev_free[i]) (void)hipEventDestroy(c->ev_free[i]);
         if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]);
