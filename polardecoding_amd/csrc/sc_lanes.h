@@ -127,63 +127,78 @@ __global__ __launch_bounds__(256, POLAR_SC_WAVES_PER_SIMD) void k_sc_lanes(SclPa
                 return all == 0xFFFFFFFFu;
             };
             // ---- levels n-1 .. 5 above this block: g at the level where the path turns right, f below it ----
-            int tf = n - 1;
-            bool live = true;   // does the subtree we are descending into hold an information leaf?
-            if (b > 0) {
-                const int d = __builtin_ctz((unsigned)b) + 5;
-                const int h = 1 << d;
-                live = !frozen_span(b, 1 << (d - 5));
-                if (live) {
-                    const uint32_t *bw = blw + (size_t)(h >> 5) * 64 + lane;   // left partial sums of level d
-                    if (d == n - 1) {   // from the channel rows: 16 consecutive elements per lane and burst
-                        for (int e0 = 0; e0 < h; e0 += 16) {
+            // One pass computes level t (g or f of level t+1, or of the channel rows at t = n-1) and, when the subtree below
+            // goes on to the left, level t-1 = f(level t) as well: the two halves of level t a level-(t-1) element needs are
+            // produced together, so level t is written once and not read back by the f step that would follow.
+            auto step = [&](int t, bool gstep, bool fuse) {
+                const int h = 1 << t, hh = h >> 1;
+                const uint32_t *bw = blw + (size_t)(h >> 5) * 64 + lane;   // left partial sums of level t (g step)
+                if (t == n - 1) {
+                    for (int e0 = 0; e0 < (fuse ? hh : h); e0 += 16) {
+                        R v[2][16];
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            if (half == 1 && !fuse) break;
+                            const int e = e0 + half * hh;
                             R a[16], c[16];
-                            const uint32_t wv = bw[(size_t)(e0 >> 5) * 64];
-                            chan16(e0, a);
-                            chan16(e0 + h, c);
+                            chan16(e, a);
+                            chan16(e + h, c);
+                            const uint32_t wv = gstep ? bw[(size_t)(e >> 5) * 64] : 0u;
 #pragma unroll
-                            for (int u = 0; u < 16; ++u) *at(h + e0 + u) = gfun<R>(a[u], c[u], (wv >> ((e0 + u) & 31)) & 1u);
+                            for (int u = 0; u < 16; ++u) {
+                                v[half][u] = gstep ? gfun<R>(a[u], c[u], (wv >> ((e + u) & 31)) & 1u) : chk_lut<R>(a[u], c[u], lut);
+                                *at(h + e + u) = v[half][u];
+                            }
                         }
-                    } else
-                    for (int e0 = 0; e0 < h; e0 += 8) {
-                        R a[8], c[8];
-                        const uint32_t wv = bw[(size_t)(e0 >> 5) * 64];
+                        if (fuse) {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            a[u] = ld_bypass(at(2 * h + e0 + u));
-                            c[u] = ld_bypass(at(2 * h + e0 + u + h));
+                            for (int u = 0; u < 16; ++u) *at(hh + e0 + u) = chk_lut<R>(v[0][u], v[1][u], lut);
                         }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) *at(h + e0 + u) = gfun<R>(a[u], c[u], (wv >> ((e0 + u) & 31)) & 1u);
                     }
-                    sync();
-                }
-                tf = d - 1;
-            }
-            for (int t = tf; t >= 5 && live; --t) {
-                const int h = 1 << t;
-                live = !frozen_span(b, 1 << (t - 5));
-                if (!live) break;
-                if (t == n - 1) {   // from the channel rows
-                    for (int e0 = 0; e0 < h; e0 += 16) {
-                        R a[16], c[16];
-                        chan16(e0, a);
-                        chan16(e0 + h, c);
+                } else {
+                    for (int e0 = 0; e0 < (fuse ? hh : h); e0 += 8) {
+                        R v[2][8];
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) *at(h + e0 + u) = chk_lut<R>(a[u], c[u], lut);
+                        for (int half = 0; half < 2; ++half) {
+                            if (half == 1 && !fuse) break;
+                            const int e = e0 + half * hh;
+                            R a[8], c[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                a[u] = ld_bypass(at(2 * h + e + u));
+                                c[u] = ld_bypass(at(2 * h + e + u + h));
+                            }
+                            const uint32_t wv = gstep ? bw[(size_t)(e >> 5) * 64] : 0u;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                v[half][u] = gstep ? gfun<R>(a[u], c[u], (wv >> ((e + u) & 31)) & 1u) : chk_lut<R>(a[u], c[u], lut);
+                                *at(h + e + u) = v[half][u];
+                            }
+                        }
+                        if (fuse) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) *at(hh + e0 + u) = chk_lut<R>(v[0][u], v[1][u], lut);
+                        }
                     }
-                } else
-                for (int e0 = 0; e0 < h; e0 += 8) {
-                    R a[8], c[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        a[u] = ld_bypass(at(2 * h + e0 + u));
-                        c[u] = ld_bypass(at(2 * h + e0 + u + h));
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) *at(h + e0 + u) = chk_lut<R>(a[u], c[u], lut);
                 }
                 sync();
+            };
+            bool live = true;   // does the subtree we are descending into hold an information leaf?
+            {
+                int t = n - 1;
+                bool gstep = false;
+                if (b > 0) {
+                    t = __builtin_ctz((unsigned)b) + 5;
+                    gstep = true;
+                }
+                while (t >= 5) {
+                    live = !frozen_span(b, 1 << (t - 5));
+                    if (!live) break;
+                    const bool fuse = (t >= 6) && !frozen_span(b, 1 << (t - 6));
+                    step(t, gstep, fuse);
+                    t -= fuse ? 2 : 1;
+                    gstep = false;
+                }
             }
             // ---- the 32-leaf block: level 5 from the scratch, levels 4..0 in registers ----
             uint32_t beta = 0, dec = 0;
