@@ -90,7 +90,10 @@ __global__ __launch_bounds__(256, POLAR_SC_WAVES_PER_SIMD) void k_sc_lanes(SclPa
 
     const int slot = blockIdx.x * Cfg::WAVES + wave, nslots = gridDim.x * Cfg::WAVES;
     R *lev = reinterpret_cast<R *>(reinterpret_cast<unsigned char *>(P.scratch) + (size_t)slot * Cfg::scratch_bytes(N)) + lane;
-    auto at = [&](int idx) -> R * { return lev + (size_t)idx * 64; };   // element idx = 2^t + e of this lane's codeword
+    // element idx = 2^t + e of this lane's codeword.  levb is lev, laundered once per 32-leaf block: otherwise every one of the
+    // ~200 statically indexed row addresses is hoisted out of the batch loop as a loop invariant and most of them are spilled
+    R *levb = lev;
+    auto at = [&](int idx) -> R * { return levb + (size_t)idx * 64; };
     auto sync = [] { __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
     const int nbatch = (P.B + 63) >> 6;
 
@@ -120,6 +123,8 @@ __global__ __launch_bounds__(256, POLAR_SC_WAVES_PER_SIMD) void k_sc_lanes(SclPa
         sync();
         uint32_t fwv = 0;   // lane l: frozen word of block (b & ~63) + l
         for (int b = 0; b < NW; ++b) {
+            levb = lev;
+            __asm__ volatile("" : "+v"(levb));
             if ((b & 63) == 0) fwv = (b + lane < NW) ? P.frozen[b + lane] : 0xFFFFFFFFu;
             auto frozen_span = [&](int b0, int nwords) -> bool {   // all leaves of blocks b0 .. b0+nwords-1 frozen?
                 uint32_t all = 0xFFFFFFFFu;
@@ -184,54 +189,88 @@ __global__ __launch_bounds__(256, POLAR_SC_WAVES_PER_SIMD) void k_sc_lanes(SclPa
                 sync();
             };
             bool live = true;   // does the subtree we are descending into hold an information leaf?
-            {
-                int t = n - 1;
-                bool gstep = false;
-                if (b > 0) {
-                    t = __builtin_ctz((unsigned)b) + 5;
-                    gstep = true;
+            int td = n - 1;
+            bool gstep = false;
+            if (b > 0) {
+                td = __builtin_ctz((unsigned)b) + 5;
+                gstep = true;
+            }
+            // Long codes (n > 7): the steps that produce level 5 run after this loop and leave it in registers
+            while (td >= 5) {
+                live = !frozen_span(b, 1 << (td - 5));
+                if (!live) break;
+                if (n > 7 && td <= 6) break;
+                const bool fuse = (td >= 6) && !frozen_span(b, 1 << (td - 6));
+                step(td, gstep, fuse);
+                td -= fuse ? 2 : 1;
+                gstep = false;
+            }
+            R x5[32];   // level 5 of this block: read by the two halves of the block and by nobody else, so never stored
+            if (live && n > 7 && td == 6) {   // level 6 from level 7 (stored: a later g step reads it), level 5 = f(level 6)
+                const bool below = !frozen_span(b, 1);
+                const uint32_t *bw = blw + (size_t)2 * 64 + lane;   // left partial sums of level 6: words 2, 3
+#pragma unroll
+                for (int e0 = 0; e0 < 32; e0 += 8) {
+                    R v[2][8];
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int e = e0 + half * 32;
+                        R a[8], c[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            a[u] = ld_bypass(at(128 + e + u));
+                            c[u] = ld_bypass(at(192 + e + u));
+                        }
+                        const uint32_t wv = gstep ? bw[(size_t)half * 64] : 0u;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            v[half][u] = gstep ? gfun<R>(a[u], c[u], (wv >> (e0 + u)) & 1u) : chk_lut<R>(a[u], c[u], lut);
+                            *at(64 + e + u) = v[half][u];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x5[e0 + u] = chk_lut<R>(v[0][u], v[1][u], lut);
                 }
-                while (t >= 5) {
-                    live = !frozen_span(b, 1 << (t - 5));
-                    if (!live) break;
-                    const bool fuse = (t >= 6) && !frozen_span(b, 1 << (t - 6));
-                    step(t, gstep, fuse);
-                    t -= fuse ? 2 : 1;
-                    gstep = false;
+                sync();
+                live = below;
+            } else if (live && n > 7 && td == 5) {   // level 5 from level 6
+                const uint32_t wv = gstep ? blw[(size_t)1 * 64 + lane] : 0u;   // left partial sums of level 5: word 1
+#pragma unroll
+                for (int e0 = 0; e0 < 32; e0 += 8) {
+                    R a[8], c[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        a[u] = ld_bypass(at(64 + e0 + u));
+                        c[u] = ld_bypass(at(96 + e0 + u));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        x5[e0 + u] = gstep ? gfun<R>(a[u], c[u], (wv >> (e0 + u)) & 1u) : chk_lut<R>(a[u], c[u], lut);
                 }
             }
-            // ---- the 32-leaf block: level 5 from the scratch, levels 4..0 in registers ----
+            // ---- the 32-leaf block: level 5 in x5, levels 4..0 in registers ----
             uint32_t beta = 0, dec = 0;
             const uint32_t fz = (uint32_t)__builtin_amdgcn_readlane((int)fwv, b & 63);
             if (live && fz != 0xFFFFFFFFu) {
                 ScLanes<R> S{lut, fz, 0u};
                 uint32_t bl = 0, br = 0;
-                // N = 32: level 5 IS the channel level, read in place like the level n-1 steps above
-                auto lvl5 = [&](int e, R *lo, R *hi) {
-                    if (n == 5) {
-                        chan16(0, lo);
-                        chan16(16, hi);
-                    } else {
+                if (n == 5) {          // N = 32: level 5 IS the channel level, read in place like the level n-1 steps above
+                    chan16(0, x5);
+                    chan16(16, x5 + 16);
+                } else if (n <= 7) {   // N = 64, 128: the generic steps above left level 5 in the scratch
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            lo[u] = ld_bypass(at(32 + u));
-                            hi[u] = ld_bypass(at(48 + u));
-                        }
-                    }
-                    (void)e;
-                };
+                    for (int u = 0; u < 32; ++u) x5[u] = ld_bypass(at(32 + u));
+                }
                 if ((fz & 0xFFFFu) != 0xFFFFu) {
-                    R l[16], lo[16], hi[16];
-                    lvl5(0, lo, hi);
+                    R l[16];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) l[e] = chk_lut<R>(lo[e], hi[e], lut);
+                    for (int e = 0; e < 16; ++e) l[e] = chk_lut<R>(x5[e], x5[16 + e], lut);
                     bl = S.template rec<4, 0>(l);
                 }
                 if ((fz >> 16) != 0xFFFFu) {
-                    R r[16], lo[16], hi[16];
-                    lvl5(0, lo, hi);
+                    R r[16];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) r[e] = gfun<R>(lo[e], hi[e], (bl >> e) & 1u);
+                    for (int e = 0; e < 16; ++e) r[e] = gfun<R>(x5[e], x5[16 + e], (bl >> e) & 1u);
                     br = S.template rec<4, 16>(r);
                 }
                 beta = (bl ^ br) | (br << 16);
