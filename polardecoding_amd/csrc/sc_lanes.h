@@ -28,6 +28,9 @@ struct ScLanesCfg {
 #ifndef POLAR_SC_WAVES_PER_SIMD
 #define POLAR_SC_WAVES_PER_SIMD 2
 #endif
+#ifndef POLAR_SC_WAVES_PER_SIMD_F32
+#define POLAR_SC_WAVES_PER_SIMD_F32 2
+#endif
     static constexpr size_t bits_bytes(int N) { return 4 * 64 * (size_t)(N / 32 + N / 64); }   // blw[NW][64] + curw[NW/2][64]
     static constexpr size_t wave_bytes(int N) { return (bits_bytes(N) + 15) & ~(size_t)15; }
     static constexpr size_t lds_bytes(int N) { return wave_bytes(N) * WAVES + Lut<R>::bytes; }
@@ -72,7 +75,7 @@ struct ScLanes {
 };
 
 template <typename R, typename IN>
-__global__ __launch_bounds__(256, POLAR_SC_WAVES_PER_SIMD) void k_sc_lanes(SclParams P)
+__global__ __launch_bounds__(256, (sizeof(R) == 4 ? POLAR_SC_WAVES_PER_SIMD_F32 : POLAR_SC_WAVES_PER_SIMD)) void k_sc_lanes(SclParams P)
 {
     using Cfg = ScLanesCfg<R>;
     const int N = P.N, n = P.n, NW = N >> 5;
