@@ -7,7 +7,7 @@ import numpy as np
 import polardecoding_amd as pa
 from oracle import oracle_py as O
 
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 2026)   # optional argument: another seed (other batch sizes and frames)
 bad = 0
 t0 = time.time()
 
