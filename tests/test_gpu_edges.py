@@ -172,3 +172,30 @@ def test_sc_channel_rows_read_in_place_any_alignment(in_dtype, shift, oracle):
     w = bits.cpu().numpy().view(np.uint32)
     uh = ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B, N).astype(np.int32)
     assert np.array_equal(uh, ref_uh)
+
+
+def test_host_batch_pipeline_equals_device_path():
+    """polar_decode_batch on a batch of several chunks (pinned staging by helper threads, asynchronous DMA, decisions unpacked
+    in the background) returns exactly what the device-pointer entry point returns on the same rows, into a caller-owned
+    output array that is reused from call to call."""
+    import torch
+    import polardecoding_amd as pa
+    N, K, B = 128, 64, 16384 * 3 + 777
+    rng = np.random.default_rng(4242)
+    sigma = 10 ** (-1.5 / 20)
+    llr = (2.0 * (1.0 + sigma * rng.standard_normal((B, N))) / sigma / sigma)
+    dec = pa.CASCL(N, K, L=8, crc_taps=pa.CRC6_TAPS)
+    out = np.full((B, N), -1, dtype=np.int32)
+    uh, pm, fl = dec.decode_batch(llr, out=out)
+    assert uh is out and set(np.unique(out).tolist()) <= {0, 1}
+    x = torch.from_numpy(llr).cuda()
+    pm_d = torch.empty(B, dtype=torch.float64, device="cuda")
+    bits = dec.decode_device(x, pm=pm_d)
+    dec.synchronize()
+    w = bits.cpu().numpy().view(np.uint32)
+    ref = ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B, N).astype(np.int32)
+    assert np.array_equal(out, ref)
+    assert np.array_equal(pm, pm_d.cpu().numpy())
+    out.fill(-1)
+    dec.decode_batch(llr[::-1].copy(), out=out)     # second call, same array, rows reversed
+    assert np.array_equal(out, ref[::-1])
