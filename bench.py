@@ -72,6 +72,36 @@ def fer_vs_snr(dec, frames):
     return rows
 
 
+def other_configs(pa, torch, device, local, snr_db):
+    """BASELINE.json's other configurations on this GPU, f64, at BASELINE's batch sizes: one launch each, timed with HIP
+    events on the decoder's stream (polar_time_decode_device), LLRs resident in HBM.  Outside the timed region; the
+    headline `value` is not affected.  (tools/bench_configs.py is the developer form of this table.)"""
+    sigma = 10 ** (-snr_db / 20)
+    rows = []
+    for name, mk, N, B in (
+            ("BP_1024: N=1024 K=512 BP 50 iterations, 2^16 frames", lambda: pa.BP(1024, 512, iterMax=50, device=local), 1024, 1 << 16),
+            ("SCL_1024: N=1024 K=512 SCL L=8, 2^16 frames", lambda: pa.SCLdecode(1024, 512, L=8, device=local), 1024, 1 << 16),
+            ("N=4096 K=2048 CA-SCL L=32 (LLR levels spill HBM), 2^15 frames per GPU",
+             lambda: pa.CASCL(4096, 2048, L=32, device=local), 4096, 1 << 15),
+            ("SC_1024: N=1024 K=512 SC, 2^18 frames", lambda: pa.SCdecode(1024, 512, device=local), 1024, 1 << 18)):
+        try:
+            d = mk()
+            y = 1.0 + sigma * torch.randn(B, N, dtype=torch.float64, device=device)
+            x = (2 * y / sigma / sigma).contiguous()
+            del y
+            ob = torch.empty((B, N // 32), dtype=torch.int32, device=device)
+            torch.cuda.synchronize()
+            d.decode_device(x, out_bits=ob)
+            d.synchronize()
+            ms = d.time_decode_device(x, ob, 2)
+            rows.append({"config": name, "kernel": d.kernel_name, "frames": B, "kernel_ms": ms, "frames_per_s": B / ms * 1e3,
+                         "frames_in_error": int((ob != 0).any(dim=1).sum().item())})
+            del d, x, ob
+        except Exception as e:  # pragma: no cover
+            rows.append({"config": name, "error": str(e)})
+    return rows
+
+
 def cpu_baseline(snr_db, seconds_target=15.0):
     """The reference's CASCL() itself (oracle/_ref/libCASCL_1024_L8.so, built from /root/reference by
     oracle/Makefile), one thread, decode call only, on frames of the same distribution."""
@@ -119,6 +149,8 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fer-sweep", action="store_true", help="skip the FER-vs-Eb/N0 points (outside the timed region)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the kernel-timed rates of BASELINE.json's other configurations (outside the timed region)")
     ap.add_argument("--one-stream", action="store_true", help="all steps on one stream (no overlap of consecutive launches)")
     ap.add_argument("--streams", type=int, default=2, help="contexts / HIP streams the steps alternate over")
     ap.add_argument("--rehearse-cpu", action="store_true",
@@ -273,6 +305,9 @@ def run(args):
     fer_sweep = None
     if rank == 0 and not args.no_fer_sweep:
         fer_sweep = fer_vs_snr(dec, B)
+    other = None
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        other = other_configs(pa, torch, device, local, args.snr)
 
     if rank == 0:
         total_frames = world * B * args.steps
@@ -308,6 +343,8 @@ def run(args):
         }
         if fer_sweep:
             out["fer_sweep"] = fer_sweep
+        if other:
+            out["other_configs"] = other
         if secondary:
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
