@@ -589,7 +589,7 @@ struct FastDec {
                 const R cb = PM + tt, cw = PM + (tt + absr(lam));
                 const uint32_t lneg = hi_word(lam) >> 31;
                 // (measured: +4 % at N = 1024, -1 ... -5 % at N = 128, where the short frames are not bound by this step)
-                if (BIG && trivial_prune(cb, cw)) {
+                if (trivial_prune(cb, cw)) {
                     bit = (uint32_t)__shfl((int)lneg, p * 8);   // pos 0 holds lambda
                     PM = cb;
                 } else {
