@@ -34,25 +34,26 @@ class _Cfg(C.Structure):
                 ("crc_systematic", C.c_int)]
 
 
-def lib_path():
-    return os.path.join(_HERE, "lib", "libpolar_hip.so")
+def lib_path(testing=False):
+    return os.path.join(_HERE, "lib", "libpolar_hip_testing.so" if testing else "libpolar_hip.so")
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """Load libpolar_hip.so (built by __graft_entry__.build()).  Raises if absent: there is no fallback."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load_library(testing=False):
+    """Load libpolar_hip.so (built by __graft_entry__.build()).  Raises if absent: there is no fallback.
+    testing=True: libpolar_hip_testing.so, the same sources plus the test-only entry points of
+    include/polar_hip_testing.h (polardecoding_amd/testing.py; never used by the product)."""
+    if testing in _libs:
+        return _libs[testing]
     # torch bundles its own HIP runtime: it must be the first one loaded in the process, or torch later
     # finds "No HIP GPUs".  torch is only plumbing here (device buffers, streams, distributed).
     try:
         import torch  # noqa: F401
     except Exception:
         pass
-    path = lib_path()
+    path = lib_path(testing)
     if not os.path.exists(path):
         raise PolarError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
     L = C.CDLL(path)
@@ -90,7 +91,7 @@ def load_library():
     L.polar_kernel_name.restype = C.c_char_p
     L.polar_kernel_name.argtypes = [vp]
     L.polar_version.restype = C.c_char_p
-    _lib = L
+    _libs[testing] = L
     return L
 
 
@@ -112,9 +113,9 @@ class Decoder:
     """One polar_ctx: a (N, K, CRC, L, algo, dtype) configuration bound to one GPU."""
 
     def __init__(self, N, K, algo, L=1, crc_taps=None, bp_iters=100, dtype=F64, device=0, info_order=None,
-                 systematic=False):
+                 systematic=False, _library=None):
         self._h = C.c_void_p()
-        self._lib = load_library()
+        self._lib = _library if _library is not None else load_library()
         self.N, self.K, self.algo, self.dtype, self.device = N, K, algo, dtype, device
         taps = np.asarray(list(crc_taps) if crc_taps else [0], dtype=np.int32)
         cfg = _Cfg()
@@ -130,14 +131,25 @@ class Decoder:
             io = np.ascontiguousarray(info_order, dtype=np.int32)
             cfg.info_order = _ptr(io, C.c_int)
         self._cfg, self._cfg_keep = cfg, (taps, io)   # kept for polar_fer_multi_gpu (the arrays the struct points to must stay alive)
-        rc = self._lib.polar_create(C.byref(cfg), C.byref(self._h))
-        if rc != 0:
-            self._h = C.c_void_p()
-            raise PolarError(f"polar_create: {self._lib.polar_strerror(rc).decode()} (rc={rc})")
+        self._create()
         A, Lr = C.c_int(), C.c_int()
         self._lib.polar_ctx_info(self._h, None, None, C.byref(A), C.byref(Lr), None, None)
         self.A, self.L = A.value, Lr.value
         self.NW = N // 32
+
+    def _create(self):
+        rc = self._lib.polar_create(C.byref(self._cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise PolarError(f"polar_create: {self._lib.polar_strerror(rc).decode()} (rc={rc})")
+
+    def _rebind(self, lib):
+        """Re-create this decoder's context inside another build of the library (polardecoding_amd/testing.py)."""
+        if lib is self._lib:
+            return
+        self.close()
+        self._lib = lib
+        self._create()
 
     @property
     def info_order(self):

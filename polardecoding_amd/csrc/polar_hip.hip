@@ -1,128 +1,28 @@
 // polar_hip.hip -- C ABI (include/polar_hip.h) over the hand-written gfx950 kernels.
-// Host side: code construction (frozen set, CRC table), kernel dispatch, buffers, stream.
-#include "../../include/polar_hip.h"
+// Host side: code construction (frozen set, CRC table), kernel dispatch, buffers, stream.  The kernels and their launch
+// code live in the k_*.hip translation units (polar_host.h declares what they export).
+#include "polar_host.h"
+#ifdef POLAR_TESTING
 #include "../../include/polar_hip_testing.h"
-
-#include <hip/hip_runtime.h>
+#endif
 
 #include <dlfcn.h>
 
-#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
 #include <mutex>
 #include <thread>
-#include <string>
-#include <vector>
 
-#include "bp_kernel.h"
-#include "bp_r4.h"
+#include "count_kernel.h"
 #include "gen_kernel.h"
-#include "probe_kernel.h"
-#include "scl_fast.h"
-#include "scl_fast2.h"
-#include "scl_fast4.h"
-#include "scl_generic.h"
-#include "scl_big.h"
-#include "sc_lanes.h"
 
 namespace {
 
 const int kQ5G[1024] = {
 #include "q5g_table.inc"
 };
-
-struct Buf {
-    void *p = nullptr;
-    size_t cap = 0;
-};
-
-}  // namespace
-
-struct polar_ctx {
-    polar_cfg cfg{};
-    int n = 0, A = 0, NW = 0, logL = 0;
-    std::vector<int> info_order;          // I[]
-    std::vector<unsigned char> frozen;    // [N]
-    std::vector<int> taps;
-    std::vector<uint32_t> h_crc_tab;      // [N]
-    uint32_t *d_frozen = nullptr;         // [NW] bit = frozen
-    uint32_t *d_info = nullptr;           // [NW] bit = unfrozen
-    uint32_t *d_crc_tab = nullptr;        // [N] or null
-    uint32_t *d_gc_rows = nullptr;        // [K] systematic CRC generator rows (D^(r+k) mod g), or null
-    uint32_t *d_frozen_override = nullptr;
-    int *d_info_order = nullptr;          // [A] for the device-side generator
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int num_cu = 0;
-    Buf in, bits, pm, flags;              // staging for the host-pointer entry points
-    Buf in2[2], bits2[2];                 // chunked host pipeline: ping-pong device buffers
-    uint32_t *h_bits[2] = {nullptr, nullptr};   // pinned host copies of the packed decisions
-    size_t h_bits_cap = 0;
-    double *h_in[2] = {nullptr, nullptr};       // pinned staging of the caller's (pageable) input chunks, big batches only
-    size_t h_in_cap = 0;
-    hipStream_t copy_stream = nullptr;    // host -> device copies overlap the decode of the previous chunk
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-    Buf scratch;                          // k_scl_fast per-wave scratch
-    Buf gen_llr, gen_u, gen_cnt;          // polar_fer_batch
-    Buf scratch_b;                        // second decode scratch: polar_fer_batch runs its two halves on two streams
-    hipStream_t stream_b = nullptr;
-    hipEvent_t ev_b = nullptr;
-    std::string last_error;
-    std::string kernel_name;
-    // kernel selection overrides, set only through include/polar_hip_testing.h (cross-checks of the tuned kernels)
-    bool force_generic = false;
-    bool use_fast2 = true;      // false: one codeword per wavefront (k_scl_fast) instead of two at N = 1024
-    bool use_fast4 = false;     // four codewords per wavefront (k_scl_fast4) at N = 1024
-    bool force_spill = false;   // no tuned L = 8 kernel; with force_generic: the global-scratch variant of k_scl_generic
-    int big_split = 0;          // 35 | 46 | 57: LDS / scratch split of k_scl_big; 0 = the measured best
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-};
-
-namespace {
-
-// Every entry point that allocates or launches runs on the ctx's device whatever the calling thread had current,
-// and leaves the thread's current device as it found it.
-struct DeviceGuard {
-    int prev = -1;
-    bool switched = false;
-    explicit DeviceGuard(int dev)
-    {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
-    }
-    ~DeviceGuard()
-    {
-        if (switched) (void)hipSetDevice(prev);
-    }
-    DeviceGuard(const DeviceGuard &) = delete;
-    DeviceGuard &operator=(const DeviceGuard &) = delete;
-};
-
-int fail(polar_ctx *c, hipError_t e, const char *what)
-{
-    if (c) c->last_error = std::string(what) + ": " + hipGetErrorString(e);
-    return POLAR_EDEVICE;
-}
-
-#define HIP_TRY(c, expr)                                   \
-    do {                                                   \
-        hipError_t e_ = (expr);                            \
-        if (e_ != hipSuccess) return fail(c, e_, #expr);   \
-    } while (0)
-
-int ensure(polar_ctx *c, Buf &b, size_t bytes)
-{
-    if (b.cap >= bytes) return POLAR_OK;
-    if (b.p) HIP_TRY(c, hipFree(b.p));
-    b.p = nullptr;
-    b.cap = 0;
-    HIP_TRY(c, hipMalloc(&b.p, bytes));
-    b.cap = bytes;
-    return POLAR_OK;
-}
 
 // Reliability order when the caller gives none: the 5G sequence restricted to < N for N <= 1024
 // (what every reference program hard-codes, SC_1024.c:42-91 / SC_128.c:41-51); for N > 1024 the
@@ -171,221 +71,9 @@ std::vector<uint32_t> make_crc_table(int N, int r, const std::vector<int> &taps,
     return tab;
 }
 
-template <typename R, typename IN, int LOGL, bool GA>
-int launch_scl_v(polar_ctx *c, const polar::SclParams &P)
-{
-    auto kern = polar::k_scl_generic<R, IN, LOGL, GA>;
-    const size_t lds = polar::scl_generic_lds_bytes<R, LOGL>(P.N, GA);
-    if (lds > 160 * 1024) return POLAR_ENOKERNEL;
-    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, lds));
-    if (occ < 1) occ = 1;
-    if (GA && occ > 8) occ = 8;
-    int grid = std::min<long long>((long long)P.B, (long long)occ * c->num_cu);
-    if (grid < 1) grid = 1;
-    polar::SclParams Q = P;
-    if (GA) {
-        const size_t bytes = sizeof(R) * (size_t)((1 << LOGL) + 1) * P.N * (size_t)grid;
-        int rc = ensure(c, c->scratch, bytes);
-        if (rc) return rc;
-        Q.scratch = c->scratch.p;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, c->stream, Q);
-    HIP_TRY(c, hipGetLastError());
-    return POLAR_OK;
-}
-
-// big lists / long codes: low LLR levels in LDS, the rest in a per-wave scratch slice (scl_big.h)
-template <typename R, typename IN, int LOGL, int TL, int TB, int RL = 0>
-int launch_big_v(polar_ctx *c, const polar::SclParams &P)
-{
-    using Cfg = polar::BigCfg<R, LOGL, TL, TB, RL>;
-    auto kern = polar::k_scl_big<R, IN, LOGL, TL, TB, RL>;
-    const size_t lds = Cfg::lds_bytes;
-    const int threads = 64 * Cfg::WAVES;
-    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds));
-    if (occ < 1) occ = 1;
-    const long long blocks_needed = ((long long)P.B + Cfg::WAVES - 1) / Cfg::WAVES;
-    int grid = std::min<long long>(blocks_needed, (long long)occ * c->num_cu);
-    if (grid < 1) grid = 1;
-    polar::SclParams Q = P;
-    int rc = ensure(c, c->scratch, Cfg::scratch_bytes(P.N) * (size_t)grid * Cfg::WAVES);
-    if (rc) return rc;
-    Q.scratch = c->scratch.p;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, Q);
-    HIP_TRY(c, hipGetLastError());
-    return POLAR_OK;
-}
-
-// SC, one codeword per lane (sc_lanes.h)
-template <typename R, typename IN>
-int launch_sc_lanes(polar_ctx *c, const polar::SclParams &P)
-{
-    using Cfg = polar::ScLanesCfg<R>;
-    auto kern = polar::k_sc_lanes<R, IN>;
-    const size_t lds = Cfg::lds_bytes(P.N);
-    const int threads = 64 * Cfg::WAVES;
-    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds));
-    if (occ < 1) occ = 1;
-    const long long batches = ((long long)P.B + 63) / 64;
-    int grid = (int)std::min<long long>((batches + Cfg::WAVES - 1) / Cfg::WAVES, (long long)occ * c->num_cu);
-    if (grid < 1) grid = 1;
-    polar::SclParams Q = P;
-    int rc = ensure(c, c->scratch, Cfg::scratch_bytes(P.N) * (size_t)grid * Cfg::WAVES);
-    if (rc) return rc;
-    Q.scratch = c->scratch.p;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, Q);
-    HIP_TRY(c, hipGetLastError());
-    return POLAR_OK;
-}
-
 static bool sc_lanes_ok(const polar_ctx *c, size_t B)
 {
     return c->cfg.algo == POLAR_ALGO_SC && !c->force_generic && c->cfg.N <= 2048 && B >= 64;
-}
-
-// the LDS / scratch split that measured best per arithmetic type (profiles/README.md)
-template <typename R, typename IN, int LOGL>
-int launch_big(polar_ctx *c, const polar::SclParams &P)
-{
-    const int use = c->big_split ? c->big_split : (sizeof(R) == 8 ? (LOGL == 5 ? 371 : 35) : 46);
-    if constexpr (LOGL == 5) {   // L = 32: LLR level TL+1 in registers (third digit of the split code; two such levels, and
-                                 // one above four LDS levels, measured slower: fewer resident wavefronts).  At the four
-                                 // wavefronts per SIMD of that kernel the LDS has room for partial-sum levels 6 and 7 too
-                                 // (371: two scratch round trips less per 128 leaves, +3 %)
-        if (use == 351) return launch_big_v<R, IN, LOGL, 3, 5, 1>(c, P);
-        if (use == 371) return launch_big_v<R, IN, LOGL, 3, 7, 1>(c, P);
-    }
-    if (use == 57) return launch_big_v<R, IN, LOGL, 5, 7>(c, P);
-    if (use == 46) return launch_big_v<R, IN, LOGL, 4, 6>(c, P);
-    return launch_big_v<R, IN, LOGL, 3, 5>(c, P);
-}
-
-// scl_big.h for SCL / CA-SCL with N >= 512, L >= 2 (shapes without a tuned kernel); else the generic kernel,
-// LDS-resident when the levels fit (160 KB per CU), global-scratch variant otherwise
-template <typename R, typename IN, int LOGL>
-int launch_scl(polar_ctx *c, const polar::SclParams &P)
-{
-    if constexpr (LOGL >= 1) {
-        if (!c->force_generic && !P.sc_mode && P.n >= 9) return launch_big<R, IN, LOGL>(c, P);
-    }
-    if (polar::scl_generic_lds_bytes<R, LOGL>(P.N, false) <= 160 * 1024 && !c->force_spill)
-        return launch_scl_v<R, IN, LOGL, false>(c, P);
-    return launch_scl_v<R, IN, LOGL, true>(c, P);
-}
-
-template <typename R, typename IN>
-int launch_scl_l(polar_ctx *c, const polar::SclParams &P)
-{
-    switch (c->logL) {
-    case 0: return launch_scl<R, IN, 0>(c, P);
-    case 1: return launch_scl<R, IN, 1>(c, P);
-    case 2: return launch_scl<R, IN, 2>(c, P);
-    case 3: return launch_scl<R, IN, 3>(c, P);
-    case 4: return launch_scl<R, IN, 4>(c, P);
-    case 5: return launch_scl<R, IN, 5>(c, P);
-    }
-    return POLAR_ENOKERNEL;
-}
-
-
-// tuned instantiations: L = 8, N in {128, 1024}
-template <typename R, typename IN, int NLOG, bool CRC_ON>
-int launch_fast(polar_ctx *c, const polar::SclParams &P)
-{
-    auto kern = polar::k_scl_fast<R, IN, NLOG, CRC_ON>;
-    constexpr int WAVES = polar::FastCfg<R, NLOG>::WAVES;
-    const size_t lds = polar::FastCfg<R, NLOG>::total;
-    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WAVES, lds));
-    if (occ < 1) occ = 1;
-    long long blocks_needed = ((long long)P.B + WAVES - 1) / WAVES;
-    int grid = (int)std::min<long long>(blocks_needed, (long long)occ * c->num_cu);
-    if (grid < 1) grid = 1;
-    polar::SclParams Q = P;
-    const size_t sc_bytes = polar::FastCfg<R, NLOG>::scratch_elems * sizeof(R) * (size_t)grid * WAVES;
-    if (sc_bytes) {
-        int rc = ensure(c, c->scratch, sc_bytes);
-        if (rc) return rc;
-        Q.scratch = c->scratch.p;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, c->stream, Q);
-    HIP_TRY(c, hipGetLastError());
-    return POLAR_OK;
-}
-
-// two codewords per wavefront (scl_fast2.h), N = 1024, L = 8
-template <typename R, typename IN, bool CRC_ON>
-int launch_fast2(polar_ctx *c, const polar::SclParams &P)
-{
-    using Cfg = polar::Fast2Cfg<R>;
-    auto kern = polar::k_scl_fast2<R, IN, CRC_ON>;
-    constexpr int WAVES = Cfg::WAVES;
-    const size_t lds = Cfg::total;
-    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WAVES, lds));
-    if (occ < 1) occ = 1;
-    const long long pairs = ((long long)P.B + 1) / 2;
-    long long blocks_needed = (pairs + WAVES - 1) / WAVES;
-    int grid = (int)std::min<long long>(blocks_needed, (long long)occ * c->num_cu);
-    if (grid < 1) grid = 1;
-    polar::SclParams Q = P;
-    const size_t sc_bytes = Cfg::scratch_elems * sizeof(R) * (size_t)grid * WAVES;
-    int rc = ensure(c, c->scratch, sc_bytes);
-    if (rc) return rc;
-    Q.scratch = c->scratch.p;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, c->stream, Q);
-    HIP_TRY(c, hipGetLastError());
-    return POLAR_OK;
-}
-
-// four codewords per wavefront (scl_fast4.h), N = 1024, L = 8
-template <typename R, typename IN, bool CRC_ON>
-int launch_fast4(polar_ctx *c, const polar::SclParams &P)
-{
-    using Cfg = polar::Fast4Cfg<R>;
-    auto kern = polar::k_scl_fast4<R, IN, CRC_ON>;
-    constexpr int WAVES = Cfg::WAVES;
-    const size_t lds = Cfg::total;
-    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WAVES, lds));
-    if (occ < 1) occ = 1;
-    const long long quads = ((long long)P.B + Cfg::CW - 1) / Cfg::CW;
-    long long blocks_needed = (quads + WAVES - 1) / WAVES;
-    int grid = (int)std::min<long long>(blocks_needed, (long long)occ * c->num_cu);
-    if (grid < 1) grid = 1;
-    polar::SclParams Q = P;
-    const size_t sc_bytes = Cfg::scratch_elems * sizeof(R) * (size_t)grid * WAVES;
-    int rc = ensure(c, c->scratch, sc_bytes);
-    if (rc) return rc;
-    Q.scratch = c->scratch.p;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, c->stream, Q);
-    HIP_TRY(c, hipGetLastError());
-    return POLAR_OK;
-}
-
-template <typename R, typename IN>
-int launch_fast_n(polar_ctx *c, const polar::SclParams &P, bool crc)
-{
-    if (P.N == 1024 && c->use_fast4) return crc ? launch_fast4<R, IN, true>(c, P) : launch_fast4<R, IN, false>(c, P);
-    if (P.N == 1024 && c->use_fast2) return crc ? launch_fast2<R, IN, true>(c, P) : launch_fast2<R, IN, false>(c, P);
-    if (P.N == 1024) return crc ? launch_fast<R, IN, 10, true>(c, P) : launch_fast<R, IN, 10, false>(c, P);
-    if (P.N == 128) return crc ? launch_fast<R, IN, 7, true>(c, P) : launch_fast<R, IN, 7, false>(c, P);
-    return POLAR_ENOKERNEL;
 }
 
 bool fast_ok(const polar_ctx *c, int in_is_f32)
@@ -396,73 +84,6 @@ bool fast_ok(const polar_ctx *c, int in_is_f32)
     if (g.L != 8 || (g.N != 1024 && g.N != 128)) return false;
     if (g.dtype == POLAR_F64 && in_is_f32) return false;
     return true;
-}
-
-// N = 1024: the register-blocked kernel (bp_r4.h), two f64 codewords per CU
-template <typename R, typename IN>
-int launch_bp_r4(polar_ctx *c, const polar::BpParams &P)
-{
-    using Cfg = polar::BpR4Cfg<R>;
-    auto kern = polar::k_bp_r4<R, IN>;
-    const size_t lds = Cfg::lds_bytes;
-    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, Cfg::THREADS, lds));
-    if (occ < 1) occ = 1;
-    int grid = (int)std::min<long long>((long long)P.B, (long long)occ * c->num_cu);
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds, c->stream, P);
-    HIP_TRY(c, hipGetLastError());
-    return POLAR_OK;
-}
-
-template <typename R, typename IN>
-int launch_bp(polar_ctx *c, const polar::BpParams &P)
-{
-    if (P.N == 1024 && !c->force_generic) return launch_bp_r4<R, IN>(c, P);
-    auto kern = polar::k_bp<R, IN>;
-    const size_t lds = polar::bp_lds_bytes<R>(P.N, P.n);
-    if (lds > 160 * 1024) {   // messages do not fit a CU's LDS: rows in global scratch
-        auto kg = polar::k_bp_global<R, IN>;
-        const size_t lds_g = 4 * (size_t)(P.N / 32) + 16 + polar::Lut<R>::bytes;
-        int grid = (int)std::min<long long>((long long)P.B, (long long)2 * c->num_cu);
-        if (grid < 1) grid = 1;
-        int rc = ensure(c, c->scratch, sizeof(R) * 2 * (size_t)(P.n + 1) * P.N * (size_t)grid);
-        if (rc) return rc;
-        hipLaunchKernelGGL(kg, dim3(grid), dim3(512), lds_g, c->stream, P, reinterpret_cast<R *>(c->scratch.p));
-        HIP_TRY(c, hipGetLastError());
-        return POLAR_OK;
-    }
-    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    const int threads = std::max(64, std::min(512, P.N / 2));
-    int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds));
-    if (occ < 1) occ = 1;
-    int grid = std::min<long long>((long long)P.B, (long long)occ * c->num_cu);
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, P);
-    HIP_TRY(c, hipGetLastError());
-    return POLAR_OK;
-}
-
-template <typename R, typename IN>
-int launch_bp_readout(polar_ctx *c, const polar::BpReadoutParams &P)
-{
-    auto kern = polar::k_bp_readout<R, IN>;
-    const size_t lds = polar::bp_readout_lds_bytes<R>(P.N, P.n);
-    if (lds > 160 * 1024) return POLAR_ENOKERNEL;
-    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    const int threads = std::max(64, std::min(256, P.N / 2));
-    int occ = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds));
-    if (occ < 1) occ = 1;
-    int grid = (int)std::min<long long>((long long)P.B, (long long)occ * c->num_cu);
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, P);
-    HIP_TRY(c, hipGetLastError());
-    return POLAR_OK;
 }
 
 int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sigma, size_t B, uint32_t *d_bits,
@@ -479,8 +100,7 @@ int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sig
         P.N = g.N; P.n = c->n; P.B = (int)B; P.iters = g.bp_iters;
         if (d_pm) HIP_TRY(c, hipMemsetAsync(d_pm, 0, B * sizeof(double), c->stream));
         if (d_flags) HIP_TRY(c, hipMemsetAsync(d_flags, 0, B * sizeof(uint32_t), c->stream));
-        if (f32) return in_is_f32 ? launch_bp<float, float>(c, P) : launch_bp<float, double>(c, P);
-        return in_is_f32 ? launch_bp<double, float>(c, P) : launch_bp<double, double>(c, P);
+        return polar_tu::bp(c, P, f32, in_is_f32 != 0);
     }
     polar::SclParams P{};
     P.in = d_in; P.sigma = sigma; P.out_bits = d_bits; P.pm = d_pm; P.flags = d_flags;
@@ -493,17 +113,21 @@ int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sig
 #ifdef POLAR_STAMPS   // diagnostic builds only (tools/): per-section cycle sums, see debug_stamps.inc
 #include "debug_stamps.inc"
 #endif
-    if (sc_lanes_ok(c, B)) {
-        if (!f32) return in_is_f32 ? launch_sc_lanes<double, float>(c, P) : launch_sc_lanes<double, double>(c, P);
-        return in_is_f32 ? launch_sc_lanes<float, float>(c, P) : launch_sc_lanes<float, double>(c, P);
-    }
+    const bool in32 = in_is_f32 != 0;
+    if (sc_lanes_ok(c, B)) return polar_tu::sc_lanes(c, P, f32, in32);
     if (fast_ok(c, in_is_f32)) {
         const bool crc = g.algo == POLAR_ALGO_CASCL;
-        if (!f32) return launch_fast_n<double, double>(c, P, crc);
-        return in_is_f32 ? launch_fast_n<float, float>(c, P, crc) : launch_fast_n<float, double>(c, P, crc);
+#ifdef POLAR_TESTING
+        if (P.N == 1024 && c->use_fast4) return polar_tu::scl_fast4(c, P, f32, in32, crc);
+#endif
+        if (P.N == 1024 && c->use_fast2) return polar_tu::scl_fast2(c, P, f32, in32, crc);
+        return polar_tu::scl_fast(c, P, f32, in32, crc);
     }
-    if (f32) return in_is_f32 ? launch_scl_l<float, float>(c, P) : launch_scl_l<float, double>(c, P);
-    return in_is_f32 ? launch_scl_l<double, float>(c, P) : launch_scl_l<double, double>(c, P);
+    // scl_big.h for SCL / CA-SCL with N >= 512, L >= 2 (shapes without a tuned kernel); else the generic kernel,
+    // LDS-resident when the levels fit (160 KB per CU), global-scratch variant otherwise
+    if (c->logL >= 1 && !c->force_generic && !P.sc_mode && P.n >= 9)
+        return f32 ? polar_tu::scl_big_f32(c, P, in32) : polar_tu::scl_big_f64(c, P, in32);
+    return polar_tu::scl_generic(c, P, f32, in32);
 }
 
 // the kernel instantiation decode_device_impl will launch for this ctx (mirrors its choices)
@@ -972,9 +596,7 @@ int polar_bp_readout_device(polar_ctx *c, const void *d_in, int in_is_f32, doubl
     P.in = d_in; P.sigma = sigma; P.out_bits = d_uhat_bits; P.frozen = c->d_frozen; P.info = c->d_info;
     P.u_bits = d_u_bits; P.E = d_E;
     P.N = c->cfg.N; P.n = c->n; P.B = (int)B; P.iters = c->cfg.bp_iters;
-    if (c->cfg.dtype == POLAR_F32)
-        return in_is_f32 ? launch_bp_readout<float, float>(c, P) : launch_bp_readout<float, double>(c, P);
-    return in_is_f32 ? launch_bp_readout<double, float>(c, P) : launch_bp_readout<double, double>(c, P);
+    return polar_tu::bp_readout(c, P, c->cfg.dtype == POLAR_F32, in_is_f32 != 0);
 }
 
 int polar_bp_readout_batch(polar_ctx *c, const double *in, double sigma, size_t B, const int *u, const int *checkpoints,
@@ -1331,6 +953,7 @@ int polar_fer_multi_gpu(const polar_cfg *cfg, int ngpus, unsigned long long seed
     return rc;
 }
 
+#ifdef POLAR_TESTING
 // ---- include/polar_hip_testing.h ----------------------------------------------------------------------------
 int polar_testing_select_kernel(polar_ctx *c, int variant)
 {
@@ -1350,37 +973,7 @@ int polar_testing_big_split(polar_ctx *c, int split)
     c->big_split = split;
     return POLAR_OK;
 }
-
-int polar_testing_math(int op, int is_f32, const void *a, const void *b, void *out, size_t n, int device)
-{
-    if (op < 0 || op > polar::PROBE_CHK_TAB || !a || !b || !out) return POLAR_EINVAL;
-    if (n == 0) return POLAR_OK;
-    DeviceGuard guard(device);
-    const size_t es = is_f32 ? 4 : 8;
-    void *da = nullptr, *db = nullptr, *d_out = nullptr;
-    int rc = POLAR_OK;
-    if (hipMalloc(&da, n * es) != hipSuccess || hipMalloc(&db, n * es) != hipSuccess || hipMalloc(&d_out, n * es) != hipSuccess)
-        rc = POLAR_ENOMEM;
-    if (!rc && (hipMemcpy(da, a, n * es, hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(db, b, n * es, hipMemcpyHostToDevice) != hipSuccess))
-        rc = POLAR_EDEVICE;
-    if (!rc) {
-        const int grid = (int)std::min<size_t>((n + 255) / 256, 1024);
-        if (is_f32)
-            hipLaunchKernelGGL(polar::k_probe_math<float>, dim3(grid), dim3(256), polar::Lut<float>::bytes + 16 + 64 * sizeof(float) + polar::Stair<float>::bytes, 0, op,
-                               (const float *)da, (const float *)db, (float *)d_out, n);
-        else
-            hipLaunchKernelGGL(polar::k_probe_math<double>, dim3(grid), dim3(256), polar::Lut<double>::bytes + 16 + 64 * sizeof(double) + polar::Stair<double>::bytes, 0, op,
-                               (const double *)da, (const double *)db, (double *)d_out, n);
-        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
-            hipMemcpy(out, d_out, n * es, hipMemcpyDeviceToHost) != hipSuccess)
-            rc = POLAR_EDEVICE;
-    }
-    if (da) (void)hipFree(da);
-    if (db) (void)hipFree(db);
-    if (d_out) (void)hipFree(d_out);
-    return rc;
-}
+#endif  // POLAR_TESTING
 
 int polar_time_decode_device(polar_ctx *c, const void *d_in, int in_is_f32, double sigma, size_t B,
                              uint32_t *d_bits, int reps, float *ms)

@@ -21,23 +21,10 @@
 #pragma once
 #include "polar_math.h"
 #include "polar_lut.h"
+#include "polar_params.h"
 
 namespace polar {
 
-struct SclParams {
-    const void *in;            // [B][N] double or float: LLRs, or y when sigma > 0
-    double sigma;              // > 0: input is y, llr = 2*y/sigma/sigma
-    uint32_t *out_bits;        // [B][N/32]
-    double *pm;                // [B] or null
-    uint32_t *flags;           // [B] or null
-    const uint32_t *frozen;    // [N/32] bit j = leaf j frozen
-    const uint32_t *crc_tab;   // [N] D^{pos(j)} mod g for unfrozen leaf j (0 for frozen); null = no CRC
-    int N, n;
-    int B;
-    int sc_mode;               // 1: plain SC decisions (SCdecode), L must be 1
-    void *scratch;             // k_scl_fast, N = 1024: per-wave global scratch (FastCfg::scratch_elems each)
-    unsigned long long *dbg;   // diagnostic builds only (-DPOLAR_STAMPS): per-section cycle sums
-};
 
 template <int LOGL>
 __device__ __forceinline__ int ptr_get(uint64_t tbl, int t)

@@ -1,5 +1,7 @@
-"""ctypes binding of include/polar_hip_testing.h -- TEST-ONLY entry points of libpolar_hip.so (kernel selection for
-cross-checks, the kernels' scalar arithmetic on chosen operands).  Used by tests/ and tools/, never by the product."""
+"""ctypes binding of include/polar_hip_testing.h -- the TEST-ONLY entry points (kernel selection for cross-checks, the
+kernels' scalar arithmetic on chosen operands).  They live in libpolar_hip_testing.so, a second build of the same sources
+with -DPOLAR_TESTING; the product library libpolar_hip.so does not export them.  A decoder handed to select_kernel /
+big_split is re-created inside the test library first.  Used by tests/ and tools/, never by the product."""
 import ctypes as C
 
 import numpy as np
@@ -12,7 +14,8 @@ OP_CHK, OP_CHK_LUT, OP_CHK_LUT1, OP_TABV, OP_PHI, OP_PHI_LUT, OP_CHK_CNT, OP_CHK
 
 def select_kernel(dec, variant):
     """dec: a polardecoding_amd Decoder.  Returns dec (its kernel_name reflects the choice)."""
-    lib = load_library()
+    lib = load_library(testing=True)
+    dec._rebind(lib)
     lib.polar_testing_select_kernel.argtypes = [C.c_void_p, C.c_int]
     rc = lib.polar_testing_select_kernel(dec._h, int(variant))
     if rc != 0:
@@ -21,7 +24,8 @@ def select_kernel(dec, variant):
 
 
 def big_split(dec, split):
-    lib = load_library()
+    lib = load_library(testing=True)
+    dec._rebind(lib)
     lib.polar_testing_big_split.argtypes = [C.c_void_p, C.c_int]
     rc = lib.polar_testing_big_split(dec._h, int(split))
     if rc != 0:
@@ -31,7 +35,7 @@ def big_split(dec, split):
 
 def math(op, a, b, dtype=np.float64, device=0):
     """The device functions of csrc/polar_math.h / polar_lut.h applied element-wise on the GPU."""
-    lib = load_library()
+    lib = load_library(testing=True)
     lib.polar_testing_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     a = np.ascontiguousarray(a, dtype=dtype).ravel()
     b = np.ascontiguousarray(np.broadcast_to(np.asarray(b, dtype=dtype), a.shape), dtype=dtype).ravel()

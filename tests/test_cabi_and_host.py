@@ -30,6 +30,26 @@ def test_every_declared_symbol_is_exported():
         assert hasattr(lib, n), f"{n} declared in polar_hip.h but not exported"
 
 
+def _exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_product_library_exports_the_c_abi_and_nothing_else():
+    """libpolar_hip.so exports exactly the polar_* functions include/polar_hip.h declares: no test-only entry point
+    (polar_testing_*, the math probe, the four-per-wave kernel live in libpolar_hip_testing.so), no C++ symbol."""
+    import polardecoding_amd as pa
+    _lib()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(REPO, "include", "polar_hip.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(polar_[a-z_0-9]+)\s*\(", hdr)))
+    assert _exported(pa.lib_path()) == declared
+    assert not [s for s in _exported(pa.lib_path()) if "testing" in s]
+    thdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(REPO, "include", "polar_hip_testing.h")).read(), flags=re.S)
+    tdecl = sorted(set(re.findall(r"\b(polar_testing_[a-z_0-9]+)\s*\(", thdr)))
+    assert len(tdecl) == 3
+    assert _exported(pa.lib_path(testing=True)) == sorted(declared + tdecl)
+
+
 def test_version_and_strerror():
     lib = _lib()
     assert b"gfx950" in lib.polar_version()

@@ -1,9 +1,9 @@
-"""Static instruction accounting for one kernel (developer tool): compile csrc/polar_hip.hip with -DPOLAR_MARKS -S
+"""Static instruction accounting for one kernel (developer tool): compile the kernel's translation unit (csrc/k_*.hip) with -DPOLAR_MARKS -S
 (--cuda-device-only) and give the .s file and the kernel's mangled name; counts the instructions between consecutive
 `; MARK name` comments, by (from, to) pair, split into VALU / SALU / LDS / VMEM / other, and the scratch (spill) traffic.
 
     hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -mllvm -amdgpu-sched-strategy=iterative-maxocc \
-          -DPOLAR_MARKS -S --cuda-device-only -o /tmp/k.s polardecoding_amd/csrc/polar_hip.hip
+          -DPOLAR_MARKS -S --cuda-device-only -o /tmp/k.s polardecoding_amd/csrc/k_fast2.hip
     python tools/count_marks.py /tmp/k.s _ZN5polar11k_scl_fast2IddLb1EEEvNS_9SclParamsE
 """
 import collections

@@ -9,6 +9,6 @@ sys.path.insert(0, REPO)
 import polardecoding_amd.api as A  # noqa: E402
 
 lib = os.path.abspath(sys.argv[1])
-A.lib_path = lambda: lib
+A.lib_path = lambda testing=False: lib
 sys.argv = sys.argv[2:]
 runpy.run_path(os.path.join(REPO, sys.argv[0]) if not os.path.isabs(sys.argv[0]) else sys.argv[0], run_name="__main__")
