@@ -84,6 +84,28 @@ const char *polar_strerror(int code);
 /* text of the last HIP error seen by this ctx ("" if none) */
 const char *polar_last_error(const polar_ctx *ctx);
 
+/* --- CRC generator-matrix file ------------------------------------------------------------------------
+ * The reference's CRC_6.dat (K = 64 rows x r = 6 entries, 0/1; row i = D^(r+i) mod g(D), column j = coefficient of
+ * D^j; UTF-16LE with BOM, CRLF, single spaces, no final newline) and, in the same layout, the literal
+ * `const int Gc[K][r]` of CASCL_1024_sys.c:48-561 that its systematic encoder sums at :776-789.  The loader takes
+ * the file's encoding as it is (also UTF-8 / ASCII, also with the braces and commas of the C literal), derives
+ * g(D) = D^r + row 0 and REJECTS the file (POLAR_EINVAL) unless every row i equals D^(r+i) mod g, g has a D^0
+ * term, all rows have the same 1..32 entries and every entry is 0 or 1. */
+typedef struct polar_crc_matrix {
+    int K;            /* rows = payload bits the matrix serves                                     */
+    int r;            /* columns = CRC length                                                      */
+    int n_taps;       /* number of exponents of g(D)                                               */
+    int taps[33];     /* exponents of g(D), ascending, incl. 0 and r: what polar_cfg.crc_taps wants */
+    uint32_t *rows;   /* [K] bit j of rows[i] = entry (i, j); malloc'ed, release with ..._free     */
+} polar_crc_matrix;
+int polar_crc_matrix_load(const char *path, polar_crc_matrix *out);
+void polar_crc_matrix_free(polar_crc_matrix *m);
+/* writes the K x r matrix of g(D) in the reference's encoding, byte for byte what CRC_6.dat holds for K = 64, {0,5,6} */
+int polar_crc_matrix_save(const char *path, int K, const int *taps, int n_taps);
+/* polar_create with r and g(D) taken from such a file (cfg->crc_r / crc_taps / n_taps are ignored; cfg->algo must be
+ * POLAR_ALGO_CASCL; cfg->K <= the file's row count).  cfg->crc_systematic = 1 is the encoder the matrix belongs to. */
+int polar_create_crc_file(const polar_cfg *cfg, const char *path, polar_ctx **out);
+
 /* --- reference-shaped single-frame call -------------------------------------------------------------
  * Identical result to  std = sigma; X(y, u_hat);  for X = SCdecode / BP / SCLdecode / CASCL
  * (SCL_1024.c:263: the per-frame call in main()).  y: N channel observations (not LLRs: the LLR
@@ -184,6 +206,15 @@ int polar_group_size(const polar_group *grp);
 int polar_group_fer_batch(polar_group *grp, unsigned long long seed, unsigned long long first_frame, double snr_db,
                           size_t frames_per_gpu, unsigned long long *block_errors, unsigned long long *bit_errors,
                           double *seconds);
+/* main()'s stop rule `for (run = 0; errBlock < BLE; run++)` (SCL_1024.c:228) over a batch decoded in shards: generate ->
+ * decode -> count on every GPU as above, then ONE ncclAllGather of the per-frame error counts (4 bytes per frame) into frame
+ * order and the cut of polar_stop_rule_cut_device on GPU 0.  *frames_used = frames consumed up to and including the one that
+ * brings the block errors to `need` (all ngpus * frames_per_gpu if the batch holds fewer; at least min_frames),
+ * *block_errors / *bit_errors = the counters over those frames (set, not added).  Independent of ngpus by construction.
+ * polar_group_create runs the two collectives on known values first and refuses the group if RCCL answers differently. */
+int polar_group_stop_rule_batch(polar_group *grp, unsigned long long seed, unsigned long long first_frame, double snr_db,
+                                size_t frames_per_gpu, unsigned need, size_t min_frames, size_t *frames_used,
+                                unsigned long long *block_errors, unsigned long long *bit_errors);
 int polar_fer_multi_gpu(const polar_cfg *cfg, int ngpus, unsigned long long seed, unsigned long long first_frame,
                         double snr_db, size_t frames_per_gpu, unsigned long long *block_errors,
                         unsigned long long *bit_errors, double *seconds);

@@ -7,9 +7,9 @@ device buffers and multi-GPU sharding.  There is no CPU fallback: everything rai
 is missing.
 """
 from .api import (ALGO_BP, ALGO_CASCL, ALGO_SC, ALGO_SCL, CRC6_TAPS, CRC24C_TAPS, F32, F64, FLAG_CRC_PASS,
-                  FLAG_RERANK, FLAG_TIE, BP, CASCL, Decoder, PolarError, SCdecode, SCLdecode, decode, lib_path, load_library,
-                  q_sequence)
+                  FLAG_RERANK, FLAG_TIE, BP, CASCL, Decoder, Group, PolarError, SCdecode, SCLdecode, decode, lib_path, load_crc_matrix, load_library,
+                  q_sequence, save_crc_matrix)
 
-__all__ = ["Decoder", "SCdecode", "BP", "SCLdecode", "CASCL", "decode", "PolarError", "load_library", "lib_path",
-           "q_sequence", "ALGO_SC", "ALGO_BP", "ALGO_SCL", "ALGO_CASCL", "F64", "F32", "CRC6_TAPS", "CRC24C_TAPS",
+__all__ = ["Decoder", "Group", "SCdecode", "BP", "SCLdecode", "CASCL", "decode", "PolarError", "load_library", "lib_path",
+           "q_sequence", "load_crc_matrix", "save_crc_matrix", "ALGO_SC", "ALGO_BP", "ALGO_SCL", "ALGO_CASCL", "F64", "F32", "CRC6_TAPS", "CRC24C_TAPS",
            "FLAG_TIE", "FLAG_CRC_PASS", "FLAG_RERANK"]

@@ -34,6 +34,11 @@ class _Cfg(C.Structure):
                 ("crc_systematic", C.c_int)]
 
 
+class _CrcMatrix(C.Structure):
+    _fields_ = [("K", C.c_int), ("r", C.c_int), ("n_taps", C.c_int), ("taps", C.c_int * 33),
+                ("rows", C.POINTER(C.c_uint32))]
+
+
 def lib_path(testing=False):
     return os.path.join(_HERE, "lib", "libpolar_hip_testing.so" if testing else "libpolar_hip.so")
 
@@ -60,6 +65,10 @@ def load_library(testing=False):
     vp, dp, ip, up = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_uint)
     L.polar_create.argtypes = [C.POINTER(_Cfg), C.POINTER(vp)]
     L.polar_destroy.argtypes = [vp]
+    L.polar_create_crc_file.argtypes = [C.POINTER(_Cfg), C.c_char_p, C.POINTER(vp)]
+    L.polar_crc_matrix_load.argtypes = [C.c_char_p, C.POINTER(_CrcMatrix)]
+    L.polar_crc_matrix_free.argtypes = [C.POINTER(_CrcMatrix)]
+    L.polar_crc_matrix_save.argtypes = [C.c_char_p, C.c_int, ip, C.c_int]
     L.polar_strerror.restype = C.c_char_p
     L.polar_strerror.argtypes = [C.c_int]
     L.polar_last_error.restype = C.c_char_p
@@ -80,6 +89,13 @@ def load_library(testing=False):
                                   C.POINTER(C.c_ulonglong)]
     L.polar_fer_multi_gpu.argtypes = [C.POINTER(_Cfg), C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_double, C.c_size_t,
                                       C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_double)]
+    L.polar_group_create.argtypes = [C.POINTER(_Cfg), C.c_int, C.POINTER(vp)]
+    L.polar_group_destroy.argtypes = [vp]
+    L.polar_group_size.argtypes = [vp]
+    L.polar_group_fer_batch.argtypes = [vp, C.c_ulonglong, C.c_ulonglong, C.c_double, C.c_size_t, C.POINTER(C.c_ulonglong),
+                                        C.POINTER(C.c_ulonglong), C.POINTER(C.c_double)]
+    L.polar_group_stop_rule_batch.argtypes = [vp, C.c_ulonglong, C.c_ulonglong, C.c_double, C.c_size_t, C.c_uint, C.c_size_t,
+                                              C.POINTER(C.c_size_t), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.polar_set_stream.argtypes = [vp, vp]
     L.polar_get_stream.restype = vp
     L.polar_get_stream.argtypes = [vp]
@@ -93,6 +109,32 @@ def load_library(testing=False):
     L.polar_version.restype = C.c_char_p
     _libs[testing] = L
     return L
+
+
+def load_crc_matrix(path):
+    """polar_crc_matrix_load: the reference's CRC_6.dat / Gc[K][r] generator-matrix file -> (taps of g(D), [K][r] uint8
+    matrix).  Raises PolarError if the file is not such a matrix (a row that is not D^(r+i) mod g, ragged, not 0/1)."""
+    lib = load_library()
+    m = _CrcMatrix()
+    rc = lib.polar_crc_matrix_load(os.fsencode(path), C.byref(m))
+    if rc != 0:
+        raise PolarError(f"polar_crc_matrix_load({path}): {lib.polar_strerror(rc).decode()} (rc={rc})")
+    try:
+        rows = np.ctypeslib.as_array(m.rows, shape=(m.K,)).copy()
+        taps = tuple(int(m.taps[i]) for i in range(m.n_taps))
+        mat = ((rows[:, None] >> np.arange(m.r, dtype=np.uint32)) & 1).astype(np.uint8)
+    finally:
+        lib.polar_crc_matrix_free(C.byref(m))
+    return taps, mat
+
+
+def save_crc_matrix(path, K, taps):
+    """polar_crc_matrix_save: the K x r generator matrix of g(D) in the bytes of the reference's CRC_6.dat."""
+    lib = load_library()
+    t = np.asarray(list(taps), dtype=np.int32)
+    rc = lib.polar_crc_matrix_save(os.fsencode(path), int(K), _ptr(t, C.c_int), len(t))
+    if rc != 0:
+        raise PolarError(f"polar_crc_matrix_save: {lib.polar_strerror(rc).decode()} (rc={rc})")
 
 
 def q_sequence(N):
@@ -113,7 +155,7 @@ class Decoder:
     """One polar_ctx: a (N, K, CRC, L, algo, dtype) configuration bound to one GPU."""
 
     def __init__(self, N, K, algo, L=1, crc_taps=None, bp_iters=100, dtype=F64, device=0, info_order=None,
-                 systematic=False, _library=None):
+                 systematic=False, crc_file=None, _library=None):
         self._h = C.c_void_p()
         self._lib = _library if _library is not None else load_library()
         self.N, self.K, self.algo, self.dtype, self.device = N, K, algo, dtype, device
@@ -130,6 +172,7 @@ class Decoder:
         if info_order is not None:
             io = np.ascontiguousarray(info_order, dtype=np.int32)
             cfg.info_order = _ptr(io, C.c_int)
+        self._crc_file = os.fsencode(crc_file) if crc_file is not None else None   # g(D) and r from a generator-matrix file
         self._cfg, self._cfg_keep = cfg, (taps, io)   # kept for polar_fer_multi_gpu (the arrays the struct points to must stay alive)
         self._create()
         A, Lr = C.c_int(), C.c_int()
@@ -138,7 +181,10 @@ class Decoder:
         self.NW = N // 32
 
     def _create(self):
-        rc = self._lib.polar_create(C.byref(self._cfg), C.byref(self._h))
+        if self._crc_file is not None:
+            rc = self._lib.polar_create_crc_file(C.byref(self._cfg), self._crc_file, C.byref(self._h))
+        else:
+            rc = self._lib.polar_create(C.byref(self._cfg), C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()
             raise PolarError(f"polar_create: {self._lib.polar_strerror(rc).decode()} (rc={rc})")
@@ -324,6 +370,52 @@ class Decoder:
         self._check(self._lib.polar_synchronize(self._h), "polar_synchronize")
 
 
+class Group:
+    """polar_group: one context per GPU of this node (devices 0 .. ngpus-1) for the configuration of `dec`, plus the RCCL
+    communicators; frames are sharded contiguously, RCCL carries only the final counters (or, for the exact stop rule,
+    the per-frame error counts)."""
+
+    def __init__(self, dec, ngpus):
+        self._lib, self._dec = dec._lib, dec
+        self._h = C.c_void_p()
+        rc = self._lib.polar_group_create(C.byref(dec._cfg), int(ngpus), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise PolarError(f"polar_group_create: {self._lib.polar_strerror(rc).decode()} (rc={rc})")
+
+    @property
+    def size(self):
+        return self._lib.polar_group_size(self._h)
+
+    def fer_batch(self, seed, first_frame, snr_db, frames_per_gpu):
+        blk, bits, sec = C.c_ulonglong(0), C.c_ulonglong(0), C.c_double(0)
+        rc = self._lib.polar_group_fer_batch(self._h, int(seed), int(first_frame), float(snr_db), int(frames_per_gpu),
+                                             C.byref(blk), C.byref(bits), C.byref(sec))
+        if rc != 0:
+            raise PolarError(f"polar_group_fer_batch: {self._lib.polar_strerror(rc).decode()} (rc={rc})")
+        return blk.value, bits.value, sec.value
+
+    def stop_rule_batch(self, seed, first_frame, snr_db, frames_per_gpu, need, min_frames=0):
+        """(frames consumed, block errors, bit errors) of the reference's stop rule over the sharded batch."""
+        used, blk, bits = C.c_size_t(0), C.c_ulonglong(0), C.c_ulonglong(0)
+        rc = self._lib.polar_group_stop_rule_batch(self._h, int(seed), int(first_frame), float(snr_db), int(frames_per_gpu),
+                                                   int(need), int(min_frames), C.byref(used), C.byref(blk), C.byref(bits))
+        if rc != 0:
+            raise PolarError(f"polar_group_stop_rule_batch: {self._lib.polar_strerror(rc).decode()} (rc={rc})")
+        return used.value, blk.value, bits.value
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.polar_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- mirrors of the reference entry points (same names, same argument meaning) -----------------------
 
 def SCdecode(N, K, **kw):
@@ -341,9 +433,13 @@ def SCLdecode(N, K, L=8, **kw):
     return Decoder(N, K, ALGO_SCL, L=L, **kw)
 
 
-def CASCL(N, K, L=8, crc_taps=CRC24C_TAPS, **kw):
+def CASCL(N, K, L=8, crc_taps=CRC24C_TAPS, crc_file=None, **kw):
     """CASCL_1024_L8.c:601 -- ``CASCL(y, u_hat)``; r and g(D) are CASCL_1024_L8.c:2-4, :19.
-    ``systematic=True`` is CASCL_1024_sys.c: same decoder, systematic CRC in the generator, K-bit error metric."""
+    ``systematic=True`` is CASCL_1024_sys.c: same decoder, systematic CRC in the generator, K-bit error metric.
+    ``crc_file``: r and g(D) from a generator-matrix file instead (the reference's CRC_6.dat; ``Gc`` of
+    CASCL_1024_sys.c:48-561 in the same layout) -- polar_create_crc_file."""
+    if crc_file is not None:
+        return Decoder(N, K, ALGO_CASCL, L=L, crc_taps=None, crc_file=crc_file, **kw)
     return Decoder(N, K, ALGO_CASCL, L=L, crc_taps=crc_taps, **kw)
 
 

@@ -731,7 +731,7 @@ int polar_generate_device(polar_ctx *c, unsigned long long seed, unsigned long l
 
 // generate -> decode -> count for B frames; the two counters stay in c->gen_cnt (device) and are copied to h[2] if h != null
 static int fer_batch_impl(polar_ctx *c, unsigned long long seed, unsigned long long first_frame, double snr_db, size_t B,
-                          unsigned long long *h)
+                          unsigned long long *h, uint32_t *d_frame_err = nullptr)
 {
     const int N = c->cfg.N, NW = c->NW;
     const bool f32 = c->cfg.dtype == POLAR_F32;
@@ -757,7 +757,7 @@ static int fer_batch_impl(polar_ctx *c, unsigned long long seed, unsigned long l
         if ((r = decode_device_impl(c, (char *)c->gen_llr.p + f0 * N * esz, f32 ? 1 : 0, 0.0, nf, (uint32_t *)c->bits.p + f0 * NW,
                                     nullptr, nullptr, c->d_frozen))) return r;
         return polar_count_errors_device(c, (uint32_t *)c->bits.p + f0 * NW, (uint32_t *)c->gen_u.p + f0 * NW, nf,
-                                         (unsigned long long *)c->gen_cnt.p, nullptr);
+                                         (unsigned long long *)c->gen_cnt.p, d_frame_err ? d_frame_err + f0 : nullptr);
     };
     if (half < B) {
         // second half on stream_b, after the counters were cleared on the main stream
@@ -804,11 +804,18 @@ struct RcclApi {
     int (*CommInitAll)(void **, int, const int *) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
+// ncclDataType_t / ncclRedOp_t as rccl.h numbers them (stable across NCCL 2.x: ncclUint32 = 3, ncclUint64 = 5,
+// ncclSum = 0).  They are NOT trusted: polar_group_create runs known values through the loaded library with exactly
+// these numbers (group_self_test) and refuses the group if the answer is not the 64-bit integer sum / the 32-bit
+// gather in rank order -- a different enum layout or ABI gives POLAR_EDEVICE, never wrong counters.
+constexpr int kNcclUint32 = 3, kNcclUint64 = 5, kNcclSum = 0;
+
 RcclApi &rccl()
 {
     static RcclApi api;
@@ -822,10 +829,11 @@ RcclApi &rccl()
         api.CommInitAll = (int (*)(void **, int, const int *))dlsym(api.handle, "ncclCommInitAll");
         api.CommDestroy = (int (*)(void *))dlsym(api.handle, "ncclCommDestroy");
         api.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(api.handle, "ncclAllReduce");
+        api.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(api.handle, "ncclAllGather");
         api.GroupStart = (int (*)())dlsym(api.handle, "ncclGroupStart");
         api.GroupEnd = (int (*)())dlsym(api.handle, "ncclGroupEnd");
         api.GetErrorString = (const char *(*)(int))dlsym(api.handle, "ncclGetErrorString");
-        api.ok = api.CommInitAll && api.CommDestroy && api.AllReduce && api.GroupStart && api.GroupEnd;
+        api.ok = api.CommInitAll && api.CommDestroy && api.AllReduce && api.AllGather && api.GroupStart && api.GroupEnd;
     });
     return api;
 }
@@ -834,7 +842,89 @@ RcclApi &rccl()
 struct polar_group {
     std::vector<polar_ctx *> ctx;
     std::vector<void *> comms;   // ncclComm_t per GPU
+    std::vector<Buf> ferr;       // per GPU: its shard's per-frame error counts (exact stop rule)
+    Buf gathered;                // GPU 0: the counts of all shards in frame order
+    Buf cut_out;                 // GPU 0: k_stop_cut's three numbers
 };
+
+extern "C++" {
+namespace {
+
+// grouped collective over the ranks of the group, one call per rank between GroupStart / GroupEnd
+template <typename F>
+bool group_collective(polar_group *g, F &&per_rank)
+{
+    RcclApi &R = rccl();
+    bool bad = R.GroupStart() != 0;
+    for (int i = 0; i < (int)g->ctx.size() && !bad; ++i) {
+        DeviceGuard guard(i);
+        bad = per_rank(i) != 0;
+    }
+    return !((R.GroupEnd() != 0) || bad);
+}
+
+bool group_sync(polar_group *g)
+{
+    bool ok = true;
+    for (int i = 0; i < (int)g->ctx.size(); ++i) {
+        DeviceGuard guard(i);
+        ok = (hipStreamSynchronize(g->ctx[(size_t)i]->stream) == hipSuccess) && ok;
+    }
+    return ok;
+}
+
+// Known answers through the loaded RCCL with the enum numbers this file uses: rank i contributes
+// {2^40 + i + 1, 3} as uint64 -- the sum must be {n 2^40 + n(n+1)/2, 3n} (a 32-bit or floating type, or a different
+// reduction, gives something else) -- and {0xC0DE0000 + i} as uint32, which must come back in rank order on every rank.
+int group_self_test(polar_group *g)
+{
+    RcclApi &R = rccl();
+    const int n = (int)g->ctx.size();
+    for (int i = 0; i < n; ++i) {
+        polar_ctx *c = g->ctx[(size_t)i];
+        DeviceGuard guard(i);
+        int rc = ensure(c, c->gen_cnt, 16);
+        if (rc) return rc;
+        if ((rc = ensure(c, g->ferr[(size_t)i], (size_t)(n + 1) * 4))) return rc;
+        const unsigned long long v[2] = {(1ull << 40) + (unsigned long long)i + 1ull, 3ull};
+        const uint32_t w = 0xC0DE0000u + (uint32_t)i;
+        if (hipMemcpyAsync(c->gen_cnt.p, v, 16, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(g->ferr[(size_t)i].p, &w, 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            return POLAR_EDEVICE;
+    }
+    if (!group_collective(g, [&](int i) {
+            void *buf = g->ctx[(size_t)i]->gen_cnt.p;
+            return R.AllReduce(buf, buf, 2, kNcclUint64, kNcclSum, g->comms[(size_t)i], g->ctx[(size_t)i]->stream);
+        }))
+        return POLAR_EDEVICE;
+    if (!group_collective(g, [&](int i) {
+            uint32_t *b = (uint32_t *)g->ferr[(size_t)i].p;
+            return R.AllGather(b, b + 1, 1, kNcclUint32, g->comms[(size_t)i], g->ctx[(size_t)i]->stream);
+        }))
+        return POLAR_EDEVICE;
+    const unsigned long long want0 = (unsigned long long)n * (1ull << 40) + (unsigned long long)n * (n + 1) / 2;
+    for (int i = 0; i < n; ++i) {
+        polar_ctx *c = g->ctx[(size_t)i];
+        DeviceGuard guard(i);
+        unsigned long long h[2] = {0, 0};
+        std::vector<uint32_t> got((size_t)n);
+        if (hipMemcpyAsync(h, c->gen_cnt.p, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(got.data(), (uint32_t *)g->ferr[(size_t)i].p + 1, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            return POLAR_EDEVICE;
+        bool ok = h[0] == want0 && h[1] == 3ull * (unsigned long long)n;
+        for (int q = 0; q < n; ++q) ok = ok && got[(size_t)q] == 0xC0DE0000u + (uint32_t)q;
+        if (!ok) {
+            c->last_error = "RCCL self-test: all-reduce(uint64, sum) / all-gather(uint32) did not return the known answer";
+            return POLAR_EDEVICE;
+        }
+    }
+    return POLAR_OK;
+}
+
+}  // namespace
+}  // extern "C++"
 
 void polar_group_destroy(polar_group *g)
 {
@@ -842,6 +932,16 @@ void polar_group_destroy(polar_group *g)
     RcclApi &R = rccl();
     for (void *cm : g->comms)
         if (cm && R.ok) (void)R.CommDestroy(cm);
+    for (size_t i = 0; i < g->ferr.size(); ++i)
+        if (g->ferr[i].p) {
+            DeviceGuard guard((int)i);
+            (void)hipFree(g->ferr[i].p);
+        }
+    {
+        DeviceGuard guard(0);
+        if (g->gathered.p) (void)hipFree(g->gathered.p);
+        if (g->cut_out.p) (void)hipFree(g->cut_out.p);
+    }
     for (polar_ctx *c : g->ctx) polar_destroy(c);
     delete g;
 }
@@ -858,6 +958,7 @@ int polar_group_create(const polar_cfg *cfg, int ngpus, polar_group **out)
     if (!g) return POLAR_ENOMEM;
     g->ctx.assign((size_t)ngpus, nullptr);
     g->comms.assign((size_t)ngpus, nullptr);
+    g->ferr.assign((size_t)ngpus, Buf{});
     std::vector<int> devs((size_t)ngpus);
     for (int i = 0; i < ngpus; ++i) {
         devs[(size_t)i] = i;
@@ -873,6 +974,11 @@ int polar_group_create(const polar_cfg *cfg, int ngpus, polar_group **out)
         polar_group_destroy(g);
         return POLAR_EDEVICE;
     }
+    const int st = group_self_test(g);   // wrong enum numbers / ABI: refuse the group instead of returning wrong counters
+    if (st) {
+        polar_group_destroy(g);
+        return st;
+    }
     *out = g;
     return POLAR_OK;
 }
@@ -886,7 +992,6 @@ int polar_group_fer_batch(polar_group *g, unsigned long long seed, unsigned long
     if (!g || !block_errors || !bit_errors) return POLAR_EINVAL;
     if (frames_per_gpu == 0) return POLAR_OK;
     RcclApi &R = rccl();
-    constexpr int ncclUint64_ = 5, ncclSum_ = 0;   // rccl.h: ncclDataType_t / ncclRedOp_t
     const int ngpus = (int)g->ctx.size();
     std::vector<int> rcs((size_t)ngpus, POLAR_OK);
     std::vector<double> secs((size_t)ngpus, 0.0);
@@ -909,16 +1014,12 @@ int polar_group_fer_batch(polar_group *g, unsigned long long seed, unsigned long
     for (int i = 0; i < ngpus; ++i)
         if (rcs[(size_t)i]) rc = rcs[(size_t)i];
     // the only exchange: sum of the two counters over the GPUs (16 bytes per rank over xGMI)
-    if (rc == POLAR_OK) {
-        bool bad = R.GroupStart() != 0;
-        for (int i = 0; i < ngpus && !bad; ++i) {
-            DeviceGuard guard(i);
+    if (rc == POLAR_OK &&
+        !group_collective(g, [&](int i) {
             void *buf = g->ctx[(size_t)i]->gen_cnt.p;
-            bad = R.AllReduce(buf, buf, 2, ncclUint64_, ncclSum_, g->comms[(size_t)i], g->ctx[(size_t)i]->stream) != 0;
-        }
-        bad = (R.GroupEnd() != 0) || bad;
-        if (bad) rc = POLAR_EDEVICE;
-    }
+            return R.AllReduce(buf, buf, 2, kNcclUint64, kNcclSum, g->comms[(size_t)i], g->ctx[(size_t)i]->stream);
+        }))
+        rc = POLAR_EDEVICE;
     if (rc == POLAR_OK) {
         unsigned long long h[2] = {0, 0};
         {
@@ -938,6 +1039,83 @@ int polar_group_fer_batch(polar_group *g, unsigned long long seed, unsigned long
     }
     if (seconds) *seconds = *std::max_element(secs.begin(), secs.end());
     return rc;
+}
+
+// The reference's sequential stop rule (`for (run = 0; errBlock < BLE; run++)`, SCL_1024.c:228) over a batch that was
+// decoded in shards: every GPU leaves the per-frame error counts of its shard on the device (k_count_errors), ONE
+// ncclAllGather of frames_per_gpu x uint32 per rank puts them in frame order on every GPU, and k_stop_cut on GPU 0 finds the
+// frame that brings the block errors to `need` exactly as polar_stop_rule_cut_device does for one GPU.  Frame f of the
+// range is the same frame for every ngpus, so the three numbers do not depend on how many GPUs shared the batch.
+int polar_group_stop_rule_batch(polar_group *g, unsigned long long seed, unsigned long long first_frame, double snr_db,
+                                size_t frames_per_gpu, unsigned need, size_t min_frames, size_t *frames_used,
+                                unsigned long long *block_errors, unsigned long long *bit_errors)
+{
+    if (!g || !frames_used || !block_errors || !bit_errors) return POLAR_EINVAL;
+    const int ngpus = (int)g->ctx.size();
+    const size_t total = frames_per_gpu * (size_t)ngpus;
+    if (frames_per_gpu == 0 || total > 0x7fffffffull || min_frames > total) return POLAR_EINVAL;
+    RcclApi &R = rccl();
+    int rc = POLAR_OK;
+    for (int i = 0; i < ngpus && !rc; ++i) {
+        DeviceGuard guard(i);
+        rc = ensure(g->ctx[(size_t)i], g->ferr[(size_t)i], std::max(frames_per_gpu, (size_t)ngpus + 1) * 4);
+    }
+    {
+        DeviceGuard guard(0);
+        if (!rc) rc = ensure(g->ctx[0], g->gathered, total * 4);
+        if (!rc) rc = ensure(g->ctx[0], g->cut_out, 3 * sizeof(unsigned long long));
+    }
+    if (rc) return rc;
+    std::vector<int> rcs((size_t)ngpus, POLAR_OK);
+    {
+        std::vector<std::thread> th;
+        for (int i = 0; i < ngpus; ++i)
+            th.emplace_back([&, i] {
+                polar_ctx *c = g->ctx[(size_t)i];
+                DeviceGuard guard(i);
+                rcs[(size_t)i] = fer_batch_impl(c, seed, first_frame + (unsigned long long)i * frames_per_gpu, snr_db,
+                                                frames_per_gpu, nullptr, (uint32_t *)g->ferr[(size_t)i].p);
+                if (rcs[(size_t)i] == POLAR_OK && hipStreamSynchronize(c->stream) != hipSuccess) rcs[(size_t)i] = POLAR_EDEVICE;
+            });
+        for (auto &t : th) t.join();
+    }
+    for (int i = 0; i < ngpus; ++i)
+        if (rcs[(size_t)i]) return rcs[(size_t)i];
+    // rank i's counts land at [i * frames_per_gpu, (i + 1) * frames_per_gpu) of every rank's receive buffer; only
+    // GPU 0's copy is used (ranks > 0 receive into a buffer of the same size, as the collective requires)
+    std::vector<Buf> recv((size_t)ngpus);
+    recv[0] = g->gathered;
+    for (int i = 1; i < ngpus && !rc; ++i) {
+        DeviceGuard guard(i);
+        if (hipMalloc(&recv[(size_t)i].p, total * 4) != hipSuccess) rc = POLAR_ENOMEM;
+    }
+    if (!rc && !group_collective(g, [&](int i) {
+            return R.AllGather(g->ferr[(size_t)i].p, recv[(size_t)i].p, frames_per_gpu, kNcclUint32, g->comms[(size_t)i],
+                               g->ctx[(size_t)i]->stream);
+        }))
+        rc = POLAR_EDEVICE;
+    if (!rc && !group_sync(g)) rc = POLAR_EDEVICE;
+    for (int i = 1; i < ngpus; ++i)
+        if (recv[(size_t)i].p) {
+            DeviceGuard guard(i);
+            (void)hipFree(recv[(size_t)i].p);
+        }
+    if (rc) return rc;
+    unsigned long long h[3] = {0, 0, 0};
+    {
+        DeviceGuard guard(0);
+        polar_ctx *c0 = g->ctx[0];
+        rc = polar_stop_rule_cut_device(c0, (const uint32_t *)g->gathered.p, total, need, min_frames,
+                                        (unsigned long long *)g->cut_out.p);
+        if (rc) return rc;
+        if (hipMemcpyAsync(h, g->cut_out.p, sizeof h, hipMemcpyDeviceToHost, c0->stream) != hipSuccess ||
+            hipStreamSynchronize(c0->stream) != hipSuccess)
+            return POLAR_EDEVICE;
+    }
+    *frames_used = (size_t)h[0];
+    *block_errors = h[1];
+    *bit_errors = h[2];
+    return POLAR_OK;
 }
 
 int polar_fer_multi_gpu(const polar_cfg *cfg, int ngpus, unsigned long long seed, unsigned long long first_frame, double snr_db,

@@ -63,9 +63,10 @@ static double ranq1(gen_state *g) /* SCL_1024.c:295-309 */
 
 typedef struct {
     int N, K, r, A, ntaps;
-    int taps[32];
+    int taps[33];
     int *I; /* info order */
     int sys; /* --sys: systematic CRC encoding and K-bit error metric (CASCL_1024_sys.c) */
+    const uint32_t *gc; /* --crc-file: the generator matrix rows as loaded (bit j of gc[i] = Gc[i][j]), else NULL */
 } code_t;
 
 /* The reference's generator is one sequential stream, but only its cheap part is: the xorshift steps and the
@@ -99,11 +100,17 @@ static void finish_frame(const code_t *c, int m, const pair_t *pr, double sigma,
     if (c->sys && c->r > 0) {
         /* CASCL_1024_sys.c:776-789: w[r..A) = payload, w[0..r) = D^r v(D) mod g (sum of the generator rows) */
         for (int i = 0; i < c->K; i++) w[c->r + i] = PN[(m + i) % 63];
+        if (c->gc) {   /* the reference's own loop: add row i of Gc for every payload bit that is 1 */
+            for (int i = 0; i < c->K; i++)
+                if (w[c->r + i])
+                    for (int j = 0; j < c->r; j++) w[j] ^= (int)((c->gc[i] >> j) & 1u);
+        } else {
         for (int i = 0; i < c->A; i++) d[i] = (i < c->r) ? 0 : w[i];
         for (int i = c->A - 1; i >= c->r; i--)
             if (d[i])
                 for (int t = 0; t < c->ntaps; t++) d[i - c->r + c->taps[t]] ^= 1;
         for (int i = 0; i < c->r; i++) w[i] = d[i];
+        }
     } else
     for (int i = 0; i < c->K; i++)
         if (PN[(m + i) % 63]) {
@@ -167,7 +174,7 @@ static const int CRC6[] = {0, 5, 6};
 
 static void usage(void)
 {
-    fprintf(stderr, "usage: polar_sim --algo sc|bp|bpr|scl|cascl --N n --K k [--L l] [--crc 24c|6] [--sys] [--seed s] [--ble b]\n"
+    fprintf(stderr, "usage: polar_sim --algo sc|bp|bpr|scl|cascl --N n --K k [--L l] [--crc 24c|6 | --crc-file m.dat] [--sys] [--seed s] [--ble b]\n"
                     "                 [--snr lo:hi:step | --snr-list a,b,..] [--batch b] [--dtype f64|f32] [--bp-iters i] [--q file] [--fn file] [--min-run m] [--fast [--gpus g]]\n");
     exit(2);
 }
@@ -181,7 +188,7 @@ int main(int argc, char **argv)
     double lo = 1.0, hi = 3.0, step = 0.5;
     double pts[64];
     int npts = 0;   /* --snr-list a,b,c: explicit Eb/N0 points (the published L = 32 log goes 1.0, 1.5, 2.0, 2.2) */
-    const char *crc = NULL, *qfile = NULL, *fnfile = NULL;
+    const char *crc = NULL, *qfile = NULL, *fnfile = NULL, *crcfile = NULL;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
         const char *v = (i + 1 < argc) ? argv[i + 1] : NULL;
@@ -195,6 +202,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--K") && v) { K = atoi(v); i++; }
         else if (!strcmp(a, "--L") && v) { L = atoi(v); i++; }
         else if (!strcmp(a, "--crc") && v) { crc = v; i++; }
+        else if (!strcmp(a, "--crc-file") && v) { crcfile = v; i++; }   /* CRC_6.dat / Gc[K][r] generator-matrix file */
         else if (!strcmp(a, "--seed") && v) { seed = strtoull(v, NULL, 10); i++; }
         else if (!strcmp(a, "--ble") && v) { ble = atoi(v); i++; }
         else if (!strcmp(a, "--batch") && v) { batch = atoi(v); i++; }
@@ -226,7 +234,20 @@ int main(int argc, char **argv)
     code_t c;
     memset(&c, 0, sizeof c);
     c.N = N; c.K = K;
-    if (algo == POLAR_ALGO_CASCL) {
+    polar_crc_matrix gcm;
+    memset(&gcm, 0, sizeof gcm);
+    if (algo == POLAR_ALGO_CASCL && crcfile) {
+        /* g(D) and r come from the generator-matrix file (the reference's CRC_6.dat, or Gc of CASCL_1024_sys.c:48-561 as
+           a file); the library has checked that every row is D^(r+i) mod g */
+        if (crc) { fprintf(stderr, "--crc and --crc-file exclude each other\n"); return 1; }
+        int lrc = polar_crc_matrix_load(crcfile, &gcm);
+        if (lrc) { fprintf(stderr, "%s: not a CRC generator matrix (%s)\n", crcfile, polar_strerror(lrc)); return 1; }
+        if (K > gcm.K) { fprintf(stderr, "%s has %d rows, --K %d needs more\n", crcfile, gcm.K, K); return 1; }
+        c.ntaps = gcm.n_taps;
+        memcpy(c.taps, gcm.taps, sizeof(int) * (size_t)c.ntaps);
+        c.r = gcm.r;
+        c.gc = gcm.rows;
+    } else if (algo == POLAR_ALGO_CASCL) {
         if (!crc) crc = (N == 128) ? "6" : "24c";
         const int *t = !strcmp(crc, "6") ? CRC6 : CRC24C;
         c.ntaps = !strcmp(crc, "6") ? 3 : 13;
@@ -273,7 +294,7 @@ int main(int argc, char **argv)
     cfg.L = L; cfg.algo = algo; cfg.bp_iters = bp_iters; cfg.info_order = qorder ? qorder + (N - c.A) : NULL; cfg.dtype = dtype; cfg.device = 0;
     cfg.crc_systematic = c.sys;
     polar_ctx *ctx = NULL;
-    int rc = polar_create(&cfg, &ctx);
+    int rc = (c.gc) ? polar_create_crc_file(&cfg, crcfile, &ctx) : polar_create(&cfg, &ctx);
     if (rc) { fprintf(stderr, "polar_create: %s\n", polar_strerror(rc)); return 1; }
     /* the library built the frozen set from the 5G sequence like the reference (I[i] = Q[N-(K+r)+i]);
        the encoder needs the same I[] */

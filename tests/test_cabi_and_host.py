@@ -222,3 +222,47 @@ def test_fn_matrix_file_format(tmp_path):
     q.write_text(" ".join(txt))
     m2, illegal2 = fnfile.read_fn(str(q), 128)
     assert illegal2 == 1 and not fnfile.is_kronecker(m2)
+
+
+def test_crc_matrix_file_loader_of_the_c_abi(tmp_path):
+    """polar_crc_matrix_load / _save (csrc/crc_matrix.hip): the reference's CRC_6.dat -- UTF-16LE, BOM, CRLF, 64 x 6 --
+    gives g(D) = D^6 + D^5 + 1 and the matrix the Python reader sees; the Gc[K][r] literal layout of
+    CASCL_1024_sys.c:48-561 (braces, commas, ASCII) loads as CRC-24C; anything that is not D^(r+i) mod g is refused."""
+    import polardecoding_amd as pa
+    from polardecoding_amd import crcfile
+    _lib()
+    golden = os.path.join(REPO, "tests", "golden", "CRC_6.dat")
+    taps, m = pa.load_crc_matrix(golden)
+    assert taps == (0, 5, 6) and m.shape == (64, 6)
+    assert np.array_equal(m, crcfile.load(golden))
+    assert np.array_equal(m, crcfile.systematic_parity_matrix(64, (0, 5, 6)))
+    out = tmp_path / "c6.dat"
+    pa.save_crc_matrix(str(out), 64, (0, 5, 6))
+    assert out.read_bytes() == open(golden, "rb").read()          # byte for byte the reference's file
+    # the layout of the C literal: `{1, 1, 1, 0, ...},` per row, plain ASCII
+    m24 = crcfile.systematic_parity_matrix(512, pa.CRC24C_TAPS)
+    lit = tmp_path / "gc.txt"
+    lit.write_text("{\n" + ",\n".join("{" + ", ".join(str(int(v)) for v in row) + "}" for row in m24) + "\n};\n")
+    taps24, back = pa.load_crc_matrix(str(lit))
+    assert taps24 == tuple(pa.CRC24C_TAPS) and np.array_equal(back, m24)
+    # refusals
+    def refuse(mat_bytes):
+        p = tmp_path / "bad.dat"
+        p.write_bytes(mat_bytes)
+        with pytest.raises(pa.PolarError):
+            pa.load_crc_matrix(str(p))
+    bad = m.copy(); bad[17, 2] ^= 1
+    refuse(crcfile.dumps(bad))                                    # one entry flipped: row 17 is not D^23 mod g
+    refuse(crcfile.dumps(m[:, :5]))                               # a column missing: rows no longer follow from row 0
+    refuse(crcfile.dumps(m).replace("1 0 0 0 0 1".encode("utf-16-le"), "1 0 0 0 0 2".encode("utf-16-le"), 1))   # not 0/1
+    refuse(b"1 0 0 0 0 1\n1 1 0 0 0\n")                         # ragged
+    refuse(b"0 1 0 0 0 1\n")                                     # g(D) without D^0
+    refuse(b"")                                                   # empty
+    refuse(b"\xff\xfe1")                                        # odd number of bytes behind the BOM
+    with pytest.raises(pa.PolarError):
+        pa.load_crc_matrix(str(tmp_path / "does_not_exist.dat"))
+    # a prefix of the rows is a valid (shorter) matrix: K = 32 payload bits
+    short = tmp_path / "c6_32.dat"
+    short.write_bytes(crcfile.dumps(m[:32]))
+    taps32, m32 = pa.load_crc_matrix(str(short))
+    assert taps32 == (0, 5, 6) and m32.shape == (32, 6)

@@ -1,9 +1,12 @@
 """GPU: device-side transmit chain (polar_generate_device) -- encoder, CRC, noise statistics,
 sharding invariance, and FER through generator + decoder against the reference's published BLER."""
 import math
+import os
 
 import numpy as np
 import pytest
+
+from conftest import GOLDEN, REPO
 
 pytestmark = pytest.mark.gpu
 
@@ -100,6 +103,57 @@ def test_generator_systematic_crc_and_payload_metric():
     sysd.count_errors_device(uh, ub, cnt)
     sysd.synchronize()
     assert cnt.tolist() == [B, B]
+
+
+def test_crc_matrix_file_drives_the_product(tmp_path):
+    """SURVEY 8f.3, file-format half: a context configured FROM the reference's generator-matrix file
+    (polar_create_crc_file on tests/golden/CRC_6.dat: N = 128, K = 64, r = 6, systematic).  The parity bits the
+    device-side transmit chain produces for 256 frames equal v * M over GF(2) with M as loaded from the file (what
+    CASCL_1024_sys.c:776-789 does with its Gc literal); the context is the one CASCL(taps = {0,5,6}) gives; and
+    `polar_sim --sys --crc-file CRC_6.dat` prints what `--sys --crc 6` prints."""
+    import subprocess
+    import torch
+    import polardecoding_amd as pa
+    from polardecoding_amd import crcfile
+    path = os.path.join(GOLDEN, "CRC_6.dat")
+    M = crcfile.load(path)                                   # [64][6], read by the independent Python reader
+    N, K, r = 128, 64, 6
+    dec = pa.CASCL(N, K, L=8, crc_file=path, systematic=True)
+    ref = pa.CASCL(N, K, L=8, crc_taps=pa.CRC6_TAPS, systematic=True)
+    assert dec.A == K + r and np.array_equal(dec.info_order, ref.info_order)
+    B = 256
+    y = torch.empty(B, N, dtype=torch.float64, device="cuda")
+    ub = torch.empty(B, N // 32, dtype=torch.int32, device="cuda")
+    dec.generate_device(11, 0, 2.0, y, ub, out_is_y=True)
+    dec.synchronize()
+    w = _unpack(ub, N)[:, dec.info_order]
+    v = w[:, r:]
+    assert v.any() and not v.all()
+    assert np.array_equal(w[:, :r], (v.astype(np.int64) @ M.astype(np.int64)) & 1)
+    # same frames, same decisions as the context built from the taps
+    y2 = torch.empty_like(y); ub2 = torch.empty_like(ub)
+    ref.generate_device(11, 0, 2.0, y2, ub2, out_is_y=True)
+    ref.synchronize()
+    assert torch.equal(y, y2) and torch.equal(ub, ub2)
+    sig = 10 ** (-2.0 / 20)
+    a = dec.decode_device(y, sigma=sig); dec.synchronize()
+    b = ref.decode_device(y2, sigma=sig); ref.synchronize()
+    assert torch.equal(a, b)
+    # a file that is not a generator matrix does not make a context
+    bad = M.copy(); bad[40, 3] ^= 1
+    p = tmp_path / "bad.dat"
+    p.write_bytes(crcfile.dumps(bad))
+    with pytest.raises(pa.PolarError):
+        pa.CASCL(N, K, L=8, crc_file=str(p), systematic=True)
+    # the C harness: exact mode (host generator sums the file's rows like the reference sums Gc), fixed seed
+    sim = os.path.join(REPO, "polardecoding_amd", "lib", "polar_sim")
+    common = [sim, "--algo", "cascl", "--N", "128", "--K", "64", "--L", "8", "--sys", "--seed", "8392", "--ble", "50",
+              "--snr", "1.0:2.0:0.5"]
+    o1 = subprocess.run(common + ["--crc-file", path], capture_output=True, text=True, check=True).stdout
+    o2 = subprocess.run(common + ["--crc", "6"], capture_output=True, text=True, check=True).stdout
+    assert o1 == o2 and o1.count("BLER") == 3
+    o3 = subprocess.run(common + ["--crc-file", str(p)], capture_output=True, text=True)
+    assert o3.returncode != 0 and "not a CRC generator matrix" in o3.stderr
 
 
 def test_generator_depends_only_on_seed_and_frame_index():
@@ -203,3 +257,50 @@ def test_fer_multi_gpu_entry_point_on_the_gpus_present():
             "--ble", "100", "--snr", "1.5:1.5:0.5", "--seed", "5"]
     a = subprocess.run(args, capture_output=True, text=True, timeout=300)
     assert a.returncode == 0 and "error block" in a.stdout
+
+
+def test_group_exact_stop_rule_over_shards():
+    """polar_group_stop_rule_batch: the reference's sequential stop rule (SCL_1024.c:228) over a batch decoded in shards --
+    per-frame error counts gathered in frame order with ONE ncclAllGather, the cut on GPU 0.  With the GPUs present (one on
+    the test box: a one-rank communicator, the collectives still run) the three numbers equal generate -> decode -> count
+    -> polar_stop_rule_cut_device on a single context over the same frame range, for a cut inside the batch, for the
+    minimum-run variant and for a batch that does not hold `need` errors.  polar_group_create's self-test (known values
+    through all-reduce(uint64, sum) and all-gather(uint32)) has passed when the group exists."""
+    import torch
+    import polardecoding_amd as pa
+    N, K = 1024, 512
+    dec = pa.CASCL(N, K, L=8)
+    n = min(torch.cuda.device_count(), 2)
+    per = 6000                      # not a multiple of anything: ragged last wave, odd shard boundary
+    total = per * n
+    seed, first, snr = 4242, 17, 1.5
+    llr = torch.empty(total, N, dtype=torch.float64, device="cuda")
+    ub = torch.empty(total, N // 32, dtype=torch.int32, device="cuda")
+    dec.generate_device(seed, first, snr, llr, ub)
+    bits = dec.decode_device(llr)
+    cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+    fe = torch.zeros(total, dtype=torch.int32, device="cuda")
+    dec.count_errors_device(bits, ub, cnt, frame_err=fe)
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    grp = pa.Group(dec, n)
+    assert grp.size == n
+    nbad = int((fe != 0).sum().item())
+    assert nbad > 60
+    for need, min_frames in ((1, 0), (25, 0), (nbad, 0), (nbad + 5, 0), (3, 2000), (40, total)):
+        dec.stop_rule_cut_device(fe, need, out, min_frames=min_frames)
+        dec.synchronize()
+        want = tuple(int(v) for v in out.tolist())
+        got = grp.stop_rule_batch(seed, first, snr, per, need, min_frames=min_frames)
+        assert got == want, (need, min_frames, got, want)
+    # literal loop on the host for one of them
+    fe_h = fe.cpu().numpy()
+    run = blk = nbits = 0
+    while blk < 25:
+        blk += fe_h[run] != 0
+        nbits += int(fe_h[run])
+        run += 1
+    assert grp.stop_rule_batch(seed, first, snr, per, 25) == (run, blk, nbits)
+    # the plain counters of the same group agree with the single context too
+    b2, e2, _ = grp.fer_batch(seed, first, snr, per)
+    assert (b2, e2) == tuple(int(v) for v in cnt.tolist())
+    grp.close()

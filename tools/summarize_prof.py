@@ -3,6 +3,11 @@
 usage: summarize_prof.py gpurun_out/profN frames_per_launch > profiles/rNN_xxx.txt"""
 import collections, csv, glob, sys
 d, frames = sys.argv[1], int(sys.argv[2])
+# gfx950 calibration (profiles/r03_counter_calibration.txt, tools/calib_traffic.hip + tools/calibrate_counters.py): on known
+# byte counts FETCH_SIZE reports exactly half of the bytes read for every access shape the decoders use (4 / 8 / 16 B per
+# lane, plain and sc1, 32-byte pieces, scratch (spill) reloads); WRITE_SIZE reports the bytes written exactly.  Raw values
+# are printed as rocprofv3 gives them, and corrected = raw x factor beside them.
+CORRECTION = {"FETCH_SIZE": 2.0, "WRITE_SIZE": 1.0}
 print(f"# rocprofv3 summary of {d} (frames per launch = {frames})")
 for f in glob.glob(f"{d}/stats/*/*_kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
@@ -52,3 +57,6 @@ for sub in sorted(glob.glob(f"{d}/pmc*")):
             for c, v in sorted(agg[kn].items()):
                 per = v / max(1, len(disp[kn]))
                 print(f"{kn:42s} {c:22s} {per:14.6g} per dispatch {per / frames:12.3f} per frame ({len(disp[kn])} dispatches)")
+                if c in CORRECTION:
+                    k = CORRECTION[c]
+                    print(f"{kn:42s} {c + ' corrected':22s} {per * k:14.6g} KiB per dispatch {per * k / frames:12.3f} KiB per frame (raw x {k:g}, gfx950 calibration)")
