@@ -125,7 +125,7 @@ void po_polar_encode(int N, const int *u, int *x)
 /* ---- decoders: generic bodies ------------------------------------------------------------- */
 
 /* statistics of the last po_scl_decode_* call (test instrumentation, see polar_oracle_impl.h) */
-static __thread int po_last_key_fallbacks, po_last_triples, po_last_phase2, po_last_trivial;
+static __thread int po_last_key_fallbacks, po_last_triples, po_last_phase2, po_last_trivial, po_last_trivial_bound, po_last_k1;
 void po_scl_last_stats(int *out)
 {
     out[0] = po_last_key_fallbacks;
@@ -137,6 +137,16 @@ void po_scl_last_prune_stats(int *out)
 {
     out[0] = po_last_phase2;
     out[1] = po_last_trivial;
+}
+/* the same plus out[2] = leaves where the cheaper sufficient test of the pair kernel shows it: the key of
+ * (max of the metrics BEFORE the leaf) + 0.65 (>= every favoured candidate, T <= 0.65) is below the key of every
+ * PM + |lambda| (<= every other candidate, T >= 0); out[3] = non-trivial leaves with exactly one fork */
+void po_scl_last_prune_stats4(int *out)
+{
+    out[0] = po_last_phase2;
+    out[1] = po_last_trivial;
+    out[2] = po_last_trivial_bound;
+    out[3] = po_last_k1;
 }
 
 #define REAL double

@@ -293,6 +293,8 @@ int FN(po_scl_decode)(const po_code *c, const REAL *llr, int L, int crc, int *u_
     po_last_triples = 0;
     po_last_phase2 = 0;
     po_last_trivial = 0;
+    po_last_trivial_bound = 0;
+    po_last_k1 = 0;
     PM[0] = 0; /* SCL_1024.c:556 */
     for (int j = 0; j < N; j++) {
         for (int k = 0; k < act; k++) lam[k] = FN(scl_leaf_llr)(&w, llr, k, j);
@@ -311,6 +313,14 @@ int FN(po_scl_decode)(const po_code *c, const REAL *llr, int L, int crc, int *u_
             }
             act *= 2;
         } else { /* phase 2: prune, SCL_1024.c:610-661 */
+            {   /* instrumentation: the sufficient test on bounds (see po_scl_last_prune_stats4) */
+                REAL mxpm = PM[0];
+                for (int k = 1; k < L; k++) if (PM[k] > mxpm) mxpm = PM[k];
+                const uint32_t bkey = FN(key32)(mxpm + (REAL)0.65);
+                int ok = 1;
+                for (int k = 0; k < L; k++) ok &= (bkey < FN(key32)(PM[k] + PO_ABS(lam[k])));
+                po_last_trivial_bound += ok;
+            }
             for (int k = 0; k < L; k++) {
                 cand[k] = PM[k] + FN(phi)(lam[k], 0);
                 cand[k + L] = PM[k] + FN(phi)(lam[k], 1);
@@ -352,6 +362,11 @@ int FN(po_scl_decode)(const po_code *c, const REAL *llr, int L, int crc, int *u_
                 else if (PM[k] >= med && PM[k + L] < med) surviv[k] = 1;
                 else if (PM[k] < med && PM[k + L] >= med) surviv[k] = 0;
                 else surviv[k] = -1;
+            }
+            {
+                int nb = 0;
+                for (int k = 0; k < L; k++) nb += (surviv[k] == 2);
+                po_last_k1 += (nb == 1);
             }
             int i = 0;
             for (int k = 0; k < L; k++) { /* :636-661 */

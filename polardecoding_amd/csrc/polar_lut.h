@@ -103,6 +103,11 @@ struct Lut {
     // T(|x|) in one LDS round trip
     __device__ __forceinline__ R tabv(R x) const
     {
+#ifdef POLAR_SENS_NOLUT   // timing sensitivity experiment only (WRONG values): no LDS traffic, same compare + select
+        const unsigned e0 = entry(x);
+        const R thr0 = R(1.05) + R(e0 & 1u);
+        return (absr(x) >= thr0) ? R(0.05) : R(0.45);
+#endif
         const unsigned e = entry(x);
         const R thr = *reinterpret_cast<const R *>(lds0 + e);
         const TP tp = *reinterpret_cast<const TP *>(lds0 + e + 32);
@@ -152,16 +157,28 @@ __device__ __forceinline__ float minabs(float a, float b)
     return m;
 }
 // m >= 0 with the sign of a*b: (m & 0x7fffffff) | ((a ^ b) & 0x80000000) as one v_bfi
+// (the sign-bit constant comes from an SGPR: VOP3 takes no literal on gfx9, and without it the compiler splits the
+// operation into v_and + v_or)
+__device__ __forceinline__ unsigned and_or_sign(unsigned x, unsigned mhi)
+{
+#ifdef POLAR_SIGN_OLD
+    return (x & 0x80000000u) | mhi;
+#else
+    unsigned r;
+    __asm__("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(0x80000000u), "v"(mhi));
+    return r;
+#endif
+}
 __device__ __forceinline__ double xor_sign(double m, double a, double b)
 {
     const unsigned x = (unsigned)(__double2hiint(a) ^ __double2hiint(b));
-    const unsigned hi = (x & 0x80000000u) | (unsigned)__double2hiint(m);  // m >= 0: v_and_or_b32
+    const unsigned hi = and_or_sign(x, (unsigned)__double2hiint(m));  // m >= 0
     return __hiloint2double((int)hi, __double2loint(m));
 }
 __device__ __forceinline__ float xor_sign(float m, float a, float b)
 {
     const unsigned x = (unsigned)(__float_as_int(a) ^ __float_as_int(b));
-    return __int_as_float((int)((x & 0x80000000u) | (unsigned)__float_as_int(m)));
+    return __int_as_float((int)and_or_sign(x, (unsigned)__float_as_int(m)));
 }
 
 // One-round-trip form: T(|s|) and T(|d|) are selected from the cell entries and subtracted here (the reference's

@@ -51,7 +51,8 @@ struct Fast2Cfg {
     static constexpr size_t off_frz = off_lut + ((Lut<R>::bytes + 15) / 16) * 16;
     static constexpr size_t off_crc = off_frz + 4 * NW;
     static constexpr size_t off_kth = off_crc + 4 * N;      // kth[mask][k] = index of the k-th set bit of mask (u8)
-    static constexpr size_t shared_bytes = off_kth + 256 * 8;
+    static constexpr size_t off_stair = off_kth + 256 * 8;  // Stair<R>: thr[8], dlt[64] (chk_idx; experiments)
+    static constexpr size_t shared_bytes = off_stair + ((Stair<R>::bytes + 15) / 16) * 16;
     // per-wave LDS
     static constexpr size_t off_bl = 0;                        // saved partial sums [2][8][NW]
     static constexpr size_t off_cw = off_bl + 4 * 2 * 8 * NW;  // working partial sums [2][8][NW]
@@ -74,6 +75,14 @@ struct Fast2Dec {
 
     R A[C::NA];      // levels 2..6
     R a1;            // level 1 (pos 0, 1)
+#ifdef POLAR_STAMPS_DECIDE
+    unsigned long long dt_rank = 0, n_rank = 0, dt_info = 0, n_info = 0;   // diagnostic: time / count of ranked steps, of all phase-2 steps
+#endif
+    R bp_s, bp_d, bp_ts, bp_td;
+    // Upper bound (+ 0.65) of the eight path metrics of the lane's codeword, the same in all its lanes, and whether it
+    // is current (wave-uniform).  See decide_t: the cheap sufficient form of the trivial-prune test.
+    R mb65;
+    bool mb_ok;   // by-products of the last level-0 check node: x + y, x - y, T(|x + y|), T(|x - y|)
     R PM;            // valid at pos 0
     uint32_t ptr, crc, bl0, fl;
     int logact;
@@ -82,6 +91,9 @@ struct Fast2Dec {
     uint32_t pos0_mask;        // ~0 in the lane that holds its path's metric (pos 0), else 0
     int cand_addr;
     Lut<R> lut;
+#ifdef POLAR_F2_IDX
+    Stair<R> st;
+#endif
     R *cand, *stg;
     uint32_t *blw, *curw, *keys;   // this lane's codeword slice of the per-wave arrays
     const uint32_t *crct;
@@ -94,16 +106,24 @@ struct Fast2Dec {
     __device__ __forceinline__ void set_pa(int t, int v) { ptr = (ptr & ~(7u << (3 * (t - 4)))) | ((uint32_t)v << (3 * (t - 4))); }
     __device__ __forceinline__ int pb(int t) const { return (ptr >> (3 * (NFA + t - 5))) & 7; }
     __device__ __forceinline__ void set_pb(int t, int v) { ptr = (ptr & ~(7u << (3 * (NFA + t - 5)))) | ((uint32_t)v << (3 * (NFA + t - 5))); }
-    // wide steps: the compact two-round-trip form in f64; in f32 (4 waves/SIMD, cheaper VALU) the one-round-trip
-    // form measured +2.4 % there too
+    // wide steps: the one-round-trip table form, as in the serial chains.  Round 2 had the compact two-round-trip form
+    // here in f64; with the by-product octets (octet()) the one-round-trip form measures +2.2 % (same-box A/B, round 3),
+    // without them +-0; in f32 it was already +2.4 %.
     __device__ __forceinline__ R chk(R a, R b) const
     {
-        if constexpr (sizeof(R) == 4) return chk_lut1<R>(a, b, lut);
-        else return chk_lut<R>(a, b, lut);
+#ifdef POLAR_F2_IDX
+        return chk_idx<R>(a, b, st);
+#endif
+#ifdef POLAR_F2_WIDE_CHK2   // the compact two-round-trip form in the wide f64 steps (round 2's choice; see below)
+        if constexpr (sizeof(R) == 8) return chk_lut<R>(a, b, lut);
+#endif
+        return chk_lut1<R>(a, b, lut);
     }
     // the narrow levels inside an octet are serial chains: the one-round-trip table form (four more issue slots,
     // one LDS latency less) measured +1.8 % there; POLAR_F2_CHK2 selects the compact form everywhere
-#ifdef POLAR_F2_CHK2
+#if defined(POLAR_F2_IDX) && POLAR_F2_IDX == 2
+    __device__ __forceinline__ R chks(R a, R b) const { return chk_idx<R>(a, b, st); }
+#elif defined(POLAR_F2_CHK2)
     __device__ __forceinline__ R chks(R a, R b) const { return chk_lut<R>(a, b, lut); }
 #else
     __device__ __forceinline__ R chks(R a, R b) const { return chk_lut1<R>(a, b, lut); }
@@ -446,6 +466,12 @@ struct Fast2Dec {
     // cb / cw = the path's metric with the favoured / the other branch, cb <= cw, valid at pos 0.
     __device__ __forceinline__ bool trivial_prune(R cb, R cw) const
     {
+        uint32_t mx;
+        return trivial_prune(cb, cw, mx);
+    }
+    // mx_out: the largest favoured key of the lane's codeword (valid in every lane)
+    __device__ __forceinline__ bool trivial_prune(R cb, R cw, uint32_t &mx_out) const
+    {
         // the largest favoured key of the lane's codeword (the other lanes of a path take no part: 0), then ONE compare per
         // path: "max favoured < min other" <=> every path's other key is above that maximum
         uint32_t mx = metric_key(cb) & pos0_mask;
@@ -458,44 +484,84 @@ struct Fast2Dec {
             auto a = __builtin_amdgcn_permlane32_swap(mx, mx, false, false);
             mx = max(a[0], a[1]);
         }
+        mx_out = mx;
         return __ballot(mx >= (metric_key(cw) | ~pos0_mask)) == 0ull;
     }
+    // smallest value whose key is above `key`: an upper bound of every metric with a key <= `key`
+    static __device__ __forceinline__ double above_key(uint32_t key, double) { return __hiloint2double((int)(key + 1u), 0); }
+    static __device__ __forceinline__ float above_key(uint32_t key, float) { return __int_as_float((int)(key + 1u)); }
     static __device__ __forceinline__ uint32_t sign_bit(double x) { return (uint32_t)__double2hiint(x) >> 31; }
     static __device__ __forceinline__ uint32_t sign_bit(float x) { return (uint32_t)__float_as_int(x) >> 31; }
 
     // ---- decision at leaf j = 8o + K; lambda valid at pos 0 ----
     template <int K>
-    __device__ __forceinline__ void decide(int o, bool frozen, R lam)
+    __device__ __forceinline__ void decide(int o, bool frozen, R lam) { decide_t<K>(o, frozen, lam, lut.tabv(lam)); }
+    // tt = T(|lambda|) (SCL_1024.c:352-359), looked up by the caller -- or, at the odd leaves, a by-product of the
+    // check node that produced the even leaf's lambda (see octet())
+    template <int K>
+    __device__ __forceinline__ void decide_t(int o, bool frozen, R lam, R tt)
     {
         const int j = 8 * o + K;
         POLAR_MARK("d2_begin");
         uint32_t crcw = 0;
+#ifdef POLAR_F2_CRC_BRANCH
         if (CRC_ON && !frozen) crcw = crct[j];
+#else
+        if (CRC_ON) crcw = crct[j];   // the table holds 0 for frozen leaves (make_crc_table): no branch around the read
+#endif
         uint32_t bit = 0;
-        const R tt = lut.tabv(lam);
         if (frozen) {
             PM += tt + negmax(lam);  // PHI(.,0)
+            mb_ok = false;
         } else {
             if (logact < 3) {
+                mb_ok = false;
                 const R ph0 = tt + negmax(lam), ph1 = tt + posmax(lam);  // PHI(.,0), PHI(.,1)
                 bit = (p >> logact) & 1;
                 PM += bit ? ph1 : ph0;
                 ++logact;
             } else {
                 POLAR_MARK("d2_phase2");
+#ifdef POLAR_STAMPS_DECIDE
+                const unsigned long long t_i0 = __builtin_amdgcn_s_memtime();
+#endif
                 // PHI of the branch lambda favours is T(|lambda|), of the other one T(|lambda|) + |lambda|
                 // (SCL_1024.c:481-502; T + 0 is T, so these ARE c0 / c1 in the order the sign of lambda says).
-                const R cb = PM + tt, cw = PM + (tt + absr(lam));
                 const uint32_t lneg = sign_bit(lam);   // lambda = +-0: cb == cw, never trivial, c0 == c1 below
+#ifdef POLAR_F2_BOUND
+                // The same test on bounds that need no reduction over the paths.  mb65 >= M + 0.65 with M >= every
+                // metric of the codeword, so every favoured candidate PM + T(|lambda|) <= mb65 (T <= 0.65, rounding is
+                // monotone); every other candidate PM + (T + |lambda|) >= PM + |lambda| (T >= 0).  If the key of mb65 is
+                // below the key of PM + |lambda| on every path, max favoured < min other: the prune is trivial.  After
+                // it every metric has grown by at most 0.65, so mb65 + 0.65 bounds the next leaf.  When the bound is
+                // stale (after a frozen leaf or a ranked step) or too loose, the exact test below decides and renews it.
+                if (mb_ok && __ballot(metric_key(mb65) >= (metric_key(PM + absr(lam)) | ~pos0_mask)) == 0ull) {
+                    bit = (uint32_t)dpp_i<0x00>((int)lneg);
+                    PM = PM + tt;
+                    mb65 = mb65 + R(0.65);
+                } else {
+#endif
+                const R cb = PM + tt, cw = PM + (tt + absr(lam));
                 // Most information leaves (85 % at 1-3 dB) prune trivially: every path keeps its favoured branch.
                 // That is certain when the largest of the eight favoured keys is below the smallest of the eight
                 // others (the 8 favoured candidates are then the 8 smallest of the 16, all strictly below the median
                 // of SCL_1024.c:619-633), and three max/min steps over the path lanes show it -- without the key
                 // exchange through LDS, the rank network and the fork bookkeeping.  Both codewords must qualify.
-                if (trivial_prune(cb, cw)) {
+                uint32_t mxk;
+                if (trivial_prune(cb, cw, mxk)) {
                     bit = (uint32_t)dpp_i<0x00>((int)lneg);   // quad_perm [0,0,0,0]: pos 0 holds lambda
                     PM = cb;
+#ifdef POLAR_F2_BOUND
+                    mb65 = above_key(mxk, R(0)) + R(0.65);   // every new metric (= cb) has a key <= mxk
+                    mb_ok = true;
+#endif
                 } else {
+#ifdef POLAR_F2_BOUND
+                mb_ok = false;
+#endif
+#ifdef POLAR_STAMPS_DECIDE
+                const unsigned long long t_r0 = __builtin_amdgcn_s_memtime();
+#endif
                 const R c0 = lneg ? cw : cb, c1 = lneg ? cb : cw;
                 const uint32_t mask = survivors(c0, c1);
                 POLAR_MARK("d2_rank_end");
@@ -518,15 +584,36 @@ struct Fast2Dec {
                     ptr = __shfl(ptr, sl);
                     crc = __shfl(crc, sl);
                     bl0 = __shfl(bl0, sl);
+#ifdef POLAR_F2_NO_BYPROD
                     if constexpr ((K & 4) == 0) { A[2] = __shfl(A[2], sl); A[3] = __shfl(A[3], sl); }  // level 3, read by g2
                     if constexpr ((K & 2) == 0) A[1] = __shfl(A[1], sl);                                // level 2, read by g1
                     if constexpr ((K & 1) == 0) a1 = __shfl(a1, sl);                                    // level 1, read by g0
+#else
+                    // what the lower-node steps still to come in this octet read: the sum / difference pairs of the
+                    // check nodes above them (octet())
+                    if constexpr ((K & 4) == 0) { A[2] = __shfl(A[2], sl); A[3] = __shfl(A[3], sl); }  // s2, d2: g at level 2 (leaf 4)
+                    if constexpr ((K & 2) == 0) { A[1] = __shfl(A[1], sl); a1 = __shfl(a1, sl); }       // s1, d1: g at level 1
+                    if constexpr ((K & 1) == 0) { bp_d = __shfl(bp_d, sl); bp_td = __shfl(bp_td, sl); } // a forked copy continues with bit 1: -d0, T(|d0|)
+#endif
                     if (refilled) { bit = 1; PM = c1s; }
                     else if (s0) { bit = 0; PM = c0; }
                     else if (s1) { bit = 1; PM = c1; }
                     else { bit = 0; PM = c0; }  // tie rule: un-refilled dead slot continues as its 0-branch
                 }
+#ifdef POLAR_STAMPS_DECIDE
+                __asm__ volatile("" :: "v"(bit), "v"(PM));
+                dt_rank += __builtin_amdgcn_s_memtime() - t_r0;
+                ++n_rank;
+#endif
                 }
+#ifdef POLAR_F2_BOUND
+                }
+#endif
+#ifdef POLAR_STAMPS_DECIDE
+                __asm__ volatile("" :: "v"(bit), "v"(PM));
+                dt_info += __builtin_amdgcn_s_memtime() - t_i0;
+                ++n_info;
+#endif
             }
             POLAR_MARK("d2_fork_end");
             if (CRC_ON) crc ^= bit ? crcw : 0u;
@@ -636,6 +723,7 @@ struct Fast2Dec {
             lg = (pos & 1) ? gg : fg;
         }
         const R pf = lut.tabv(lf) + negmax(lf), pg = lut.tabv(lg) + negmax(lg);  // PHI(lambda_k, 0)
+        mb_ok = false;
         PM += pf;
         PM += quadp<0x55>(pf);  // lane 1 of the quad
         PM += quadp<0xAA>(pf);  // lane 2
@@ -652,9 +740,71 @@ struct Fast2Dec {
         }
     }
 
-    // ---- the 8 leaves of octet o; A[2], A[3] hold the level-3 LLRs ----
+    // Check node that keeps what it computed on the way: CHK(x, y) = sgn min + (T(|s|) - T(|d|)) with s = x + y,
+    // d = x - y (SCL_1024.c:350-373).  The lower-node update of the same pair is cL +- cU = y +- x (:412-416), i.e.
+    // s for partner bit 0 and y - x = -d for bit 1 -- same operands, one rounding, so the value is the one g_bit()
+    // computes (a zero may come out as -0 where y - x gives +0; a zero lambda decides nothing: PHI adds no penalty
+    // either way, it never prunes trivially, and c0 == c1 in the ranking).  T(|s|), T(|d|) are the staircase values the
+    // odd leaf's PHI needs.  So inside an octet every g step and every second table look-up is a by-product.
+    struct ChkBp { R v, s, d, ts, td; };
+    __device__ __forceinline__ ChkBp chk_bp(R x, R y) const
+    {
+        ChkBp r;
+        r.s = x + y;
+        r.d = x - y;
+        r.ts = lut.tabv(r.s);
+        r.td = lut.tabv(r.d);
+        r.v = xor_sign(minabs(x, y), x, y) + (r.ts - r.td);
+        return r;
+    }
+    // s or -d by the partner bit at position sh of w
+    static __device__ __forceinline__ R g_sel(R sum, R dif, uint32_t w, int sh)
+    {
+        const bool b = (w >> sh) & 1u;
+        return b ? -dif : sum;
+    }
+    template <int K>   // leaves K (even) and K + 1 from the level-1 pair in a1 (pos 0: x, pos 1: y)
+    __device__ __forceinline__ void leaf_pair(int o, uint32_t fm, R x1)
+    {
+        const ChkBp q = chk_bp(x1, quadp<0xB1>(x1));
+        bp_d = q.d;
+        bp_td = q.td;
+        decide<K>(o, (fm >> K) & 1, q.v);
+        // leaf K + 1: g0 with the bit just decided (bit 1 of bl0, set_bit_k<even>); a slot refilled by a fork took
+        // bp_d / bp_td of its source and continues with bit 1, every other slot still has its own q.s / q.ts
+        const bool b1 = (bl0 >> 1) & 1u;
+        decide_t<K + 1>(o, (fm >> (K + 1)) & 1, b1 ? -bp_d : q.s, b1 ? bp_td : q.ts);
+    }
     __device__ __forceinline__ void octet(int o, uint32_t fm)
     {
+#ifndef POLAR_F2_NO_BYPROD
+        // level 2: f of (A[2], A[3]); its sum / difference stay in A[2], A[3] for the g step at leaf 4
+        {
+            const R s2 = A[2] + A[3], d2 = A[2] - A[3];
+            const R v2 = xor_sign(minabs(A[2], A[3]), A[2], A[3]) + (lut.tabv(s2) - lut.tabv(d2));
+            A[2] = s2;
+            A[3] = d2;
+            // level 1: f; sum / difference in (A[1], a1) for the g steps at leaves 2 and 6
+            const R y2 = quadp<0x4E>(v2);
+            const R s1 = v2 + y2, d1 = v2 - y2;
+            const R v1 = xor_sign(minabs(v2, y2), v2, y2) + (lut.tabv(s1) - lut.tabv(d1));
+            A[1] = s1;
+            a1 = d1;
+            leaf_pair<0>(o, fm, v1);
+        }
+        leaf_pair<2>(o, fm, g_sel(A[1], a1, bl0, 2 + pos));
+        {
+            const R v2 = g_sel(A[2], A[3], bl0, 4 + pos);   // level 2, g
+            const R y2 = quadp<0x4E>(v2);
+            const R s1 = v2 + y2, d1 = v2 - y2;
+            const R v1 = xor_sign(minabs(v2, y2), v2, y2) + (lut.tabv(s1) - lut.tabv(d1));
+            A[1] = s1;
+            a1 = d1;
+            leaf_pair<4>(o, fm, v1);
+        }
+        leaf_pair<6>(o, fm, g_sel(A[1], a1, bl0, 2 + pos));
+        return;
+#endif
         // leaf 0: f2 f1 f0
         A[1] = chks(A[2], A[3]);
         a1 = chks(A[1], quadp<0x4E>(A[1]));
@@ -691,13 +841,20 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
     using C = Fast2Cfg<R>;
     constexpr int N = C::N, NW = C::NW, L = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef POLAR_F2_WAVE_VGPR
     const int wave = threadIdx.x >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the per-wave LDS base is scalar
+#endif
     unsigned char *base = smem + C::shared_bytes + (size_t)wave * C::per_wave;
     uint32_t *frz = reinterpret_cast<uint32_t *>(smem + C::off_frz);
     uint32_t *crct = reinterpret_cast<uint32_t *>(smem + C::off_crc);
     unsigned char *kth = smem + C::off_kth;
 
     Lut<R>::build(smem + C::off_lut, threadIdx.x, blockDim.x);
+#ifdef POLAR_F2_IDX
+    Stair<R>::build(smem + C::off_stair, threadIdx.x, blockDim.x);
+#endif
     for (int i = threadIdx.x; i < NW; i += blockDim.x) frz[i] = P.frozen[i];
     if (CRC_ON)
         for (int i = threadIdx.x; i < N; i += blockDim.x) crct[i] = P.crc_tab[i];
@@ -720,6 +877,9 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
     s.pos0_mask = s.pos == 0 ? 0xFFFFFFFFu : 0u;
     s.gl = s.lane & 7;
     s.lut.bind(smem + C::off_lut);
+#ifdef POLAR_F2_IDX
+    s.st.bind(smem + C::off_stair);
+#endif
     s.crct = crct;
     s.kth = kth;
     s.blw = reinterpret_cast<uint32_t *>(base + C::off_bl) + s.c * 8 * NW;
@@ -775,6 +935,8 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
         for (int r = 0; r < C::NA; ++r) s.A[r] = R(0);
         s.fl = 0;
         s.logact = 0;
+        s.mb65 = R(0);
+        s.mb_ok = false;
         uint32_t fword = 0;
 
         STAMP(2);
@@ -854,6 +1016,9 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
         STAMP(6);
     }
 #ifdef POLAR_STAMPS
+#ifdef POLAR_STAMPS_DECIDE   // buckets 0 / 1: time and count (x 1000) of the ranked steps, 7 / 6: of all phase-2 information leaves
+    tsec[0] = s.dt_rank; tsec[1] = s.n_rank * 1000; tsec[7] += s.dt_info; tsec[6] = s.n_info * 1000;
+#endif
     if (P.dbg && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&P.dbg[i], tsec[i]);
 #endif

@@ -19,6 +19,8 @@
 int polar_create(const polar_cfg *a, polar_ctx **b) { (void)a; (void)b; return POLAR_EDEVICE; }
 void polar_destroy(polar_ctx *a) { (void)a; }
 const char *polar_strerror(int a) { (void)a; return ""; }
+int polar_crc_matrix_load(const char *a, polar_crc_matrix *b) { (void)a; (void)b; return POLAR_EDEVICE; }
+int polar_create_crc_file(const polar_cfg *a, const char *b, polar_ctx **c) { (void)a; (void)b; (void)c; return POLAR_EDEVICE; }
 const char *polar_last_error(const polar_ctx *a) { (void)a; return ""; }
 int polar_info_order(const polar_ctx *a, int *b, int c) { (void)a; (void)b; (void)c; return POLAR_EDEVICE; }
 int polar_fer_batch(polar_ctx *a, unsigned long long b, unsigned long long c, double d, size_t e, unsigned long long *f,
