@@ -5,11 +5,11 @@
 namespace {
 
 // big lists / long codes: low LLR levels in LDS, the rest in a per-wave scratch slice (scl_big.h)
-template <typename R, typename IN, int LOGL, int TL, int TB, int RL = 0>
+template <typename R, typename IN, int LOGL, int TL, int TB, int RL = 0, int CH = 0>
 int launch_big_v(polar_ctx *c, const polar::SclParams &P)
 {
     using Cfg = polar::BigCfg<R, LOGL, TL, TB, RL>;
-    auto kern = polar::k_scl_big<R, IN, LOGL, TL, TB, RL>;
+    auto kern = polar::k_scl_big<R, IN, LOGL, TL, TB, RL, CH>;
     const size_t lds = Cfg::lds_bytes;
     const int threads = 64 * Cfg::WAVES;
     HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -39,7 +39,14 @@ int launch_big(polar_ctx *c, const polar::SclParams &P)
                                  // wavefronts per SIMD of that kernel the LDS has room for partial-sum levels 6 and 7 too
                                  // (371: two scratch round trips less per 128 leaves, +3 %)
         if (use == 351) return launch_big_v<R, IN, LOGL, 3, 5, 1>(c, P);
-        if (use == 371) return launch_big_v<R, IN, LOGL, 3, 7, 1>(c, P);
+        if (use == 371) {
+            // long codes in f64 (BASELINE config 5, N = 4096): the f chains of the upper levels in one pass, three
+            // wavefronts per SIMD (scl_big.h, chain()); N = 1024 keeps the four-wavefront kernel
+            if constexpr (sizeof(R) == 8) {
+                if (P.N >= 2048) return launch_big_v<R, IN, LOGL, 3, 7, 1, 1>(c, P);
+            }
+            return launch_big_v<R, IN, LOGL, 3, 7, 1>(c, P);
+        }
     }
     if (use == 57) return launch_big_v<R, IN, LOGL, 5, 7>(c, P);
     if (use == 46) return launch_big_v<R, IN, LOGL, 4, 6>(c, P);

@@ -105,8 +105,11 @@ __device__ __forceinline__ void wave_sync() { __asm__ volatile("s_waitcnt vmcnt(
 
 // One register level (RL = 1) is worth it only at four wavefronts per SIMD (128 VGPRs): the decoder is a chain of dependent
 // round trips and its rate follows the number of resident wavefronts.
-template <typename R, typename IN, int LOGL, int TLv, int TBv, int RLv = 0>
-__global__ __launch_bounds__(256, RLv == 1 ? 4 : 1) void k_scl_big(SclParams P)
+// CH = 1: the chains of f steps below a step at level >= 7 run in one pass (chain() below).  It needs more registers for its
+// loads in flight, so the kernel then runs three wavefronts per SIMD; measured on N = 4096, L = 32 (BASELINE config 5): +9 %,
+// a third less fabric read traffic; on N = 1024, L = 32 the four-wavefront kernel without it stays ahead.
+template <typename R, typename IN, int LOGL, int TLv, int TBv, int RLv = 0, int CH = 0>
+__global__ __launch_bounds__(256, RLv == 1 ? (CH ? 3 : 4) : 1) void k_scl_big(SclParams P)
 {
 #ifdef POLAR_STAMPS
     unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -214,30 +217,152 @@ __global__ __launch_bounds__(256, RLv == 1 ? 4 : 1) void k_scl_big(SclParams P)
                     }
                 }
             } else {
-                // t = 4 or 5 (only when TL < 5): 64 / 2^t leaders per pass, source slots fetched by lane
+                // t = 4 or 5 (only when TL < 5): 64 / 2^t leaders per pass, source slots fetched by lane.  The loads of
+                // UL passes go out before the first result is needed (one round trip per UL passes instead of one per pass).
                 const int total = nlead << t;   // elements over all leaders
-                for (int it = 0; it < total; it += 64) {
-                    const int idx = it + lane;
-                    const bool on = idx < total;
-                    const int q = on ? tbl[idx >> t] : 0, e = idx & (h - 1);
-                    const int ss = __shfl(my_src, q * S);
-                    const R *src = hiA + (size_t)ss * N + 2 * h;
-                    const R a = ld_bypass(src + e), b = ld_bypass(src + e + h);
-                    R r;
-                    if (gstep) {
-                        const uint32_t w0 = __shfl(bl0, q * S);                 // t = 4: bits 16 + e of the register word
-                        const int bs = __shfl(my_bits, q * S);
-                        const uint32_t wv = (t == 5) ? blw[bs * WL + 1] : (w0 >> h);
-                        r = gfun<R>(a, b, (wv >> e) & 1);
-                    } else {
-                        r = chk_lut<R>(a, b, lut);
+                constexpr int UL = 4;
+                for (int it = 0; it < total; it += 64 * UL) {
+                    R a[UL], b[UL];
+                    uint32_t wv[UL];
+                    int qq[UL];
+#pragma unroll
+                    for (int u = 0; u < UL; ++u) {
+                        const int idx = it + 64 * u + lane;
+                        const bool on = idx < total;
+                        const int q = on ? tbl[idx >> t] : 0, e = idx & (h - 1);
+                        qq[u] = q;
+                        const int ss = __shfl(my_src, q * S);
+                        const R *src = hiA + (size_t)ss * N + 2 * h;
+                        a[u] = ld_bypass(src + e);
+                        b[u] = ld_bypass(src + e + h);
+                        wv[u] = 0;
+                        if (gstep) {
+                            const uint32_t w0 = __shfl(bl0, q * S);                 // t = 4: bits 16 + e of the register word
+                            const int bs = __shfl(my_bits, q * S);
+                            wv[u] = (t == 5) ? blw[bs * WL + 1] : (w0 >> h);
+                        }
                     }
-                    if (on) hiA[(size_t)q * N + h + e] = r;
+#pragma unroll
+                    for (int u = 0; u < UL; ++u) {
+                        const int idx = it + 64 * u + lane;
+                        const int e = idx & (h - 1);
+                        const R r = gstep ? gfun<R>(a[u], b[u], (wv[u] >> e) & 1) : chk_lut<R>(a[u], b[u], lut);
+                        if (idx < total) hiA[(size_t)qq[u] * N + h + e] = r;
+                    }
                 }
             }
             if (p < act) ptrA = ptr_set<LOGL>(ptrA, t, leader);
             wave_sync();
             BIG_STAMP((t >= 6) ? 1 : 2);
+        };
+        // ---- levels d, d-1, ..., 6 in ONE pass (d >= 7): the step at level d (g, or f from the channel row), then the f steps
+        // below it without reading a row back.  A lane owns the elements lane + 64 k of every row, and element k of level
+        // t-1 is CHK of elements k and k + 2^(t-7) of level t -- both in the same lane -- so the whole f chain of a node is
+        // a reduction tree inside each lane.  The 2^(d-6) elements of level d are visited in bit-reversed order of k, which
+        // makes every pair, every pair of pairs, ... consecutive: one pending value per level, no row read back.  Every row
+        // is still WRITTEN (the g step of its right child reads it later).  Same operations on the same operands as one
+        // bulk() per level; a third of the fabric traffic of the upper levels (the read-back of every f step) and all but
+        // one of the full drains per chain are gone.  The leaders of the step at level d are the leaders of every level
+        // below it in the chain (f steps do not look at partial sums).
+        auto chain = [&](int d, bool gstep) {
+            const int h = 1 << d;
+            const int my_src = (d + 1 == n) ? 0 : ptr_get<LOGL>(ptrA, d + 1);
+            const int my_bits = ptr_get<LOGL>(ptrB, d);
+            const int key = !gstep ? my_src : (my_src | (my_bits << LOGL));
+            int leader = p;
+            for (int k = act - 1; k >= 0; --k)
+                if (__builtin_amdgcn_readlane(key, k * S) == key) leader = k;
+            const uint64_t m_lead = __ballot(pos == 0 && p < act && leader == p);
+            const int nlead = __popcll(m_lead);
+            if (pos == 0 && p < act && leader == p) tbl[__popcll(m_lead & below)] = p;
+            __asm__ volatile("" ::: "memory");
+            const int LV = d - 6, K = 1 << LV;
+            for (int li = 0; li < nlead; ++li) {
+                const int q = __builtin_amdgcn_readfirstlane(tbl[li]);
+                const int ss = __builtin_amdgcn_readlane(my_src, q * S);
+                const int bs = __builtin_amdgcn_readlane(my_bits, q * S);
+                // wave-uniform bases, 32-bit lane offsets (scalar-base addressing: no 64-bit address registers per lane)
+                const R *src = (d + 1 == n) ? chg : hiA + (size_t)ss * N + 2 * h;
+                R *rows = hiA + (size_t)q * N;                   // level t of leader q: rows[2^t + 64 k + lane]
+                const uint32_t *gw = gbl + (size_t)bs * NW;
+                const uint32_t *lw = blw + bs * WL;
+                // element k of level d (g or f), stored
+                auto top_ld = [&](int k, R &a, R &b, uint32_t &wv) {
+                    a = ld_bypass(src + (unsigned)(64 * k + lane));
+                    b = ld_bypass(src + (unsigned)(64 * k + h + lane));
+                    if (gstep) {
+                        const int wi = (h + 64 * k + lane) >> 5;
+                        wv = (d > TB) ? ld_bypass(gw + wi) : lw[wi];
+                    }
+                };
+                auto top_ev = [&](int k, R a, R b, uint32_t wv) -> R {
+                    const R v = gstep ? gfun<R>(a, b, (wv >> (lane & 31)) & 1) : chk_lut<R>(a, b, lut);
+                    rows[(unsigned)(h + 64 * k + lane)] = v;
+                    return v;
+                };
+                auto fnode = [&](int t, int k, R x, R y) -> R {   // element k of level t from its two parents, stored
+                    const R v = chk_lut<R>(x, y, lut);
+                    rows[(unsigned)((1 << t) + 64 * k + lane)] = v;
+                    return v;
+                };
+                if (LV == 1) {
+                    R a0, b0, a1, b1;
+                    uint32_t w0 = 0, w1 = 0;
+                    top_ld(0, a0, b0, w0);
+                    top_ld(1, a1, b1, w1);
+                    const R v0 = top_ev(0, a0, b0, w0), v1 = top_ev(1, a1, b1, w1);
+                    (void)fnode(6, 0, v0, v1);
+                }
+                else if (LV >= 3) {   // eight elements of level d per round: sixteen loads in flight per lane
+                    R pend3 = R(0), pend4 = R(0);
+                    for (int i = 0; i < K; i += 8) {
+                        const int k0 = (int)(__brev((unsigned)i) >> (32 - LV));
+                        const int e2 = K >> 1, e4 = K >> 2, e8 = K >> 3;
+                        const int kk[8] = {k0, k0 + e2, k0 + e4, k0 + e4 + e2, k0 + e8, k0 + e8 + e2, k0 + e8 + e4, k0 + e8 + e4 + e2};
+                        R a[8], b[8];
+                        uint32_t wv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) top_ld(kk[u], a[u], b[u], wv[u]);
+                        R w[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const R v0 = top_ev(kk[2 * u], a[2 * u], b[2 * u], wv[2 * u]);
+                            const R v1 = top_ev(kk[2 * u + 1], a[2 * u + 1], b[2 * u + 1], wv[2 * u + 1]);
+                            w[u] = fnode(d - 1, kk[2 * u], v0, v1);
+                        }
+                        const R x0 = fnode(d - 2, kk[0], w[0], w[1]), x1 = fnode(d - 2, kk[4], w[2], w[3]);
+                        R x = fnode(d - 3, k0, x0, x1);
+                        if (LV > 3) {
+                            if (!((i >> 3) & 1)) {
+                                pend3 = x;
+                            } else {
+                                x = fnode(d - 4, (int)(__brev((unsigned)(i & ~15)) >> (32 - LV)), pend3, x);
+                                if (LV > 4) {
+                                    if (!((i >> 4) & 1)) pend4 = x;
+                                    else (void)fnode(d - 5, 0, pend4, x);
+                                }
+                            }
+                        }
+                    }
+                }
+                else {   // LV == 2: the four elements of level 8, in the order 0, 2, 1, 3
+                    R a[4], b[4];
+                    uint32_t wv[4] = {0, 0, 0, 0};
+                    top_ld(0, a[0], b[0], wv[0]);
+                    top_ld(2, a[1], b[1], wv[1]);
+                    top_ld(1, a[2], b[2], wv[2]);
+                    top_ld(3, a[3], b[3], wv[3]);
+                    const R v0 = top_ev(0, a[0], b[0], wv[0]), v1 = top_ev(2, a[1], b[1], wv[1]);
+                    const R w01 = fnode(d - 1, 0, v0, v1);
+                    const R v2 = top_ev(1, a[2], b[2], wv[2]), v3 = top_ev(3, a[3], b[3], wv[3]);
+                    const R w23 = fnode(d - 1, 1, v2, v3);
+                    (void)fnode(d - 2, 0, w01, w23);
+                }
+            }
+            if (p < act)
+                for (int t = 6; t <= d; ++t) ptrA = ptr_set<LOGL>(ptrA, t, leader);
+            wave_sync();
+            BIG_STAMP(1);
         };
         // ---- level t in (TL, TL+RL]: the path's own S lanes, rows in registers (ra: level TL+1, rb: level TL+2) ----
         // No leader sharing here (every path evaluates its own row: VALU work instead of a scratch round trip per step).
@@ -380,6 +505,19 @@ __global__ __launch_bounds__(256, RLv == 1 ? 4 : 1) void k_scl_big(SclParams P)
 #undef POLAR_LOW_CASE
         };
 
+        // The register levels are dead when a chain starts: every path is about to rewrite its own rows on the way down (f
+        // steps at every level below the chain) before anybody reads them again.  Saying so frees their registers for the
+        // chain's loads in flight (their writes are predicated on p < act, which hides that from the compiler).
+        auto kill_regs = [&]() {
+            if constexpr (RL >= 1) {
+#pragma unroll
+                for (int k = 0; k < PER1; ++k) ra[k] = R(0);
+            }
+            if constexpr (RL >= 2) {
+#pragma unroll
+                for (int k = 0; k < PER2; ++k) rb[k] = R(0);
+            }
+        };
         for (int j = 0; j < N; ++j) {
             // per-leaf constants, one coalesced vector load per 64 leaves (a scalar load per leaf would put its whole
             // latency in front of the next LDS wait: both count on lgkmcnt)
@@ -390,12 +528,22 @@ __global__ __launch_bounds__(256, RLv == 1 ? 4 : 1) void k_scl_big(SclParams P)
             // ================= LLR of leaf j for every active path =================
             BIG_MARK("big_llr");
             int tf = n - 1;
-            if (j > 0) {
+            if (CH && TR <= 5 && j == 0 && n - 1 >= 7) {
+                kill_regs();
+                chain(n - 1, false);
+                tf = 5;
+            } else if (j > 0) {
                 const int d = __builtin_ctz((unsigned)j);
+                if (CH && TR <= 5 && d >= 7) {
+                    kill_regs();
+                    chain(d, true);
+                    tf = 5;
+                } else {
                 if (d > TR) bulk(d, true);
                 else if (d > TL) reg(d, true);
                 else low(d, true);
                 tf = d - 1;
+                }
             }
             for (int t = tf; t >= 0; --t) {
                 if (t > TR) bulk(t, false);

@@ -109,8 +109,15 @@ def test_bench_under_torchrun_single_rank():
     for key in ("metric", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                 "config", "roofline"):
         assert key in d, key
-    assert d["scaling"] == "weak" and d["dtype"] == "f64" and d["roofline"]["bound"] == "hbm"
-    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["scaling"] == "weak" and d["dtype"] == "f64"
+    # the path is VALU-issue bound: the HBM figures of the contract are reported, the binding roofline is named
+    r = d["roofline"]
+    assert r["bound"] == "valu" and r["unit"] == "GB/s" and 0 < r["frac"] < 0.05
+    lo, hi = r["valu"]["achieved_frac"]
+    assert 0.05 < lo < hi < 1.0 and r["valu"]["lane_ops_per_frame"] == [1267712, 1882112]
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["name"] == "cascl_1024_l8"
+    assert d["rccl_ranks"] == 1 and len(d["devices"]) == 1 and d["devices"][0]   # what RCCL really summed over, and on what
+    assert d["vs_baseline"] and d["vs_baseline"] > 1000
 
 
 def test_two_host_threads_two_contexts(oracle):
