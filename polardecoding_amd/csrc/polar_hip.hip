@@ -201,7 +201,9 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
     // hipMemcpyAsync from it is a single-threaded staging copy inside the runtime (about 18 GB/s) that blocks this thread.
     // Batches of several chunks are therefore staged HERE, by helper threads, into pinned buffers, and cross PCIe as true
     // asynchronous DMA.
-    const size_t CH = 16384;
+    // chunk: 16384 frames, but at most 128 MiB of input (N = 1024: 16384 frames; N = 4096: 4096), so that the two pinned
+    // staging buffers and the two device buffers stay at 256 MiB each whatever the block length
+    const size_t CH = std::max<size_t>(256, std::min<size_t>(16384, ((size_t)128 << 20) / ((size_t)N * sizeof(double))));
     const size_t nch = (B + CH - 1) / CH;
     const size_t chf = std::min(B, CH);
     for (int i = 0; i < 2; ++i) {
@@ -209,6 +211,7 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
         if ((rc = ensure(c, c->bits2[i], chf * NW * sizeof(uint32_t)))) return rc;
     }
     if (c->h_bits_cap < chf * NW * sizeof(uint32_t)) {
+        c->h_bits_cap = 0;   // a failure below leaves "nothing allocated", not the old size over freed pointers
         for (int i = 0; i < 2; ++i) {
             if (c->h_bits[i]) HIP_TRY(c, hipHostFree(c->h_bits[i]));
             c->h_bits[i] = nullptr;
@@ -226,6 +229,7 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
     }
     const bool staged = nch >= 3;
     if (staged && c->h_in_cap < chf * N * sizeof(double)) {
+        c->h_in_cap = 0;
         for (int i = 0; i < 2; ++i) {
             if (c->h_in[i]) HIP_TRY(c, hipHostFree(c->h_in[i]));
             c->h_in[i] = nullptr;

@@ -190,10 +190,26 @@ def test_bench_launches_its_own_ranks_under_gloo():
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 3 and d["rehearsal"] is True
     assert d["counter_sum"] == [3, 30]          # (1 + 2, 10 + 20): the SUM all-reduce over both ranks
     assert d["value"] is None                   # a rehearsal measures nothing
+    # what the N-rank line says about the collective backend: the number of ranks an all-reduce of ones really summed
+    # over, and every rank's device name gathered through the same backend
+    assert d["rccl_ranks"] == 2 and len(d["devices"]) == 2 and "rank 1" in d["devices"][1]
+    assert d["config"]["name"] == "cascl_1024_l8" and d["config"]["frames_per_gpu_per_step"] == 1 << 17
+    # BASELINE config 5 has an N-rank line of its own: --config cascl_4096_l32, 2^15 frames per GPU (2^18 over 8)
+    out5 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--rehearse-cpu",
+                           "--config", "cascl_4096_l32"], capture_output=True, text=True, timeout=600, env=env)
+    assert out5.returncode == 0, out5.stderr[-3000:]
+    d5 = json.loads([l for l in out5.stdout.splitlines() if l.startswith("{")][0])
+    assert d5["n_gpus"] == 2 and d5["rccl_ranks"] == 2 and "N=4096 K=2048 CA-SCL L=32" in d5["metric"]
+    assert d5["config"]["name"] == "cascl_4096_l32" and d5["config"]["frames_per_gpu_per_step"] == 1 << 15
     # a launcher that started a different number of ranks than --gpus says is an error, not a silent n_gpus = 1
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--rehearse-cpu"],
                          capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0"))
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+    # an EXTERNAL launcher (torchrun started by somebody else, not bench.py's own launch()) gets the dmabuf-IPC setting RCCL
+    # needs on this image too: run() puts it into the environment before torch is imported
+    src = open(os.path.join(REPO, "bench.py")).read()
+    body = src[src.index("def run(args):"):]
+    assert body.index('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")') < body.index("import torch")
 
 
 def test_fn_matrix_file_format(tmp_path):

@@ -22,6 +22,7 @@ def llrs(B, N):
 CONFIGS = [
     ("SC_1024", lambda: pa.SCdecode(1024, 512, dtype=dt), 1024, 1 << 18),
     ("BP_1024_50it", lambda: pa.BP(1024, 512, iterMax=50, dtype=dt), 1024, 1 << 16),
+    ("BP_128_100it", lambda: pa.BP(128, 64, iterMax=100, dtype=dt), 128, 1 << 18),
     ("SCL_1024_L8", lambda: pa.SCLdecode(1024, 512, L=8, dtype=dt), 1024, 1 << 16),
     ("CASCL_1024_L8", lambda: pa.CASCL(1024, 512, L=8, dtype=dt), 1024, 1 << 17),
     ("CASCL_128_L8", lambda: pa.CASCL(128, 64, L=8, crc_taps=pa.CRC6_TAPS, dtype=dt), 128, 1 << 18),

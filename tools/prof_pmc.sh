@@ -4,7 +4,7 @@
 # The program itself follows `--` (python3 bench.py ...), no env/bash -c hop.
 OUT=${1:-gpurun_out/prof}
 shift
-ARGS=${@:-"--steps 3 --warmup 1 --no-cpu-baseline --no-fer-sweep --no-other-configs"}
+ARGS=${@:-"--steps 3 --warmup 1 --no-cpu-baseline --no-fer-sweep --no-other-configs --no-end-to-end"}
 R=$GRAFT_REPO_ROOT
 PROG=${POLAR_PROF_PROG:-bench.py}   # e.g. tools/bench_configs.py with ARGS "--only BP"
 mkdir -p $R/$OUT
