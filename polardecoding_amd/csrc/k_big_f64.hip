@@ -43,7 +43,10 @@ int launch_big(polar_ctx *c, const polar::SclParams &P)
             // long codes in f64 (BASELINE config 5, N = 4096): the f chains of the upper levels in one pass, three
             // wavefronts per SIMD (scl_big.h, chain()); N = 1024 keeps the four-wavefront kernel
             if constexpr (sizeof(R) == 8) {
-                if (P.N >= 2048) return launch_big_v<R, IN, LOGL, 3, 7, 1, 1>(c, P);
+#ifndef POLAR_BIG_CH   // 0: without chain() (four wavefronts per SIMD), for same-box comparisons (tools/variant.py)
+#define POLAR_BIG_CH 1
+#endif
+                if (POLAR_BIG_CH && P.N >= 2048) return launch_big_v<R, IN, LOGL, 3, 7, 1, POLAR_BIG_CH>(c, P);
             }
             return launch_big_v<R, IN, LOGL, 3, 7, 1>(c, P);
         }

@@ -345,18 +345,22 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? 3 : 4) : 1) void k_scl_big(Sc
                         }
                     }
                 }
-                else {   // LV == 2: the four elements of level 8, in the order 0, 2, 1, 3
-                    R a[4], b[4];
-                    uint32_t wv[4] = {0, 0, 0, 0};
-                    top_ld(0, a[0], b[0], wv[0]);
-                    top_ld(2, a[1], b[1], wv[1]);
-                    top_ld(1, a[2], b[2], wv[2]);
-                    top_ld(3, a[3], b[3], wv[3]);
-                    const R v0 = top_ev(0, a[0], b[0], wv[0]), v1 = top_ev(2, a[1], b[1], wv[1]);
-                    const R w01 = fnode(d - 1, 0, v0, v1);
-                    const R v2 = top_ev(1, a[2], b[2], wv[2]), v3 = top_ev(3, a[3], b[3], wv[3]);
-                    const R w23 = fnode(d - 1, 1, v2, v3);
-                    (void)fnode(d - 2, 0, w01, w23);
+                else {   // LV == 2: the four elements of level 8 in one round (same loop shape as above: K = 4, one trip)
+                    for (int i = 0; i < K; i += 4) {
+                        const int k0 = (int)(__brev((unsigned)i) >> (32 - LV));
+                        const int k1 = k0 + (K >> 1), k2 = k0 + (K >> 2), k3 = k2 + (K >> 1);
+                        R a[4], b[4];
+                        uint32_t wv[4] = {0, 0, 0, 0};
+                        top_ld(k0, a[0], b[0], wv[0]);
+                        top_ld(k1, a[1], b[1], wv[1]);
+                        top_ld(k2, a[2], b[2], wv[2]);
+                        top_ld(k3, a[3], b[3], wv[3]);
+                        const R v0 = top_ev(k0, a[0], b[0], wv[0]), v1 = top_ev(k1, a[1], b[1], wv[1]);
+                        const R w01 = fnode(d - 1, k0, v0, v1);
+                        const R v2 = top_ev(k2, a[2], b[2], wv[2]), v3 = top_ev(k3, a[3], b[3], wv[3]);
+                        const R w23 = fnode(d - 1, k2, v2, v3);
+                        (void)fnode(d - 2, k0, w01, w23);
+                    }
                 }
             }
             if (p < act)

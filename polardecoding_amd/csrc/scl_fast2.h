@@ -98,8 +98,51 @@ struct Fast2Dec {
     uint32_t *blw, *curw, *keys;   // this lane's codeword slice of the per-wave arrays
     const uint32_t *crct;
     const unsigned char *kth;
-    R *scr;          // this codeword's scratch
-    const IN *src;   // this codeword's input row
+    // Scratch and input rows are read and written through buffer instructions: a wave-uniform resource descriptor
+    // (4 SGPRs) plus a 32-bit per-lane byte offset.  The two codewords of a wavefront differ by a constant offset, so no
+    // lane holds a 64-bit address: round 2's per-lane pointers were spilled and re-loaded from the stack in front of every
+    // load of the scratch-level steps (a dependent memory round trip per load, in the same in-order vmcnt queue).
+    __amdgpu_buffer_rsrc_t rs_scr;   // this wavefront's scratch (both codewords)
+    __amdgpu_buffer_rsrc_t rs_in;    // the input rows of the wavefront's two codewords
+    unsigned cscr;                   // element offset of the lane's codeword in the scratch: c * scratch_cw
+    unsigned csrc;                   // element offset of the lane's codeword's input row: 0 or N
+    static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
+    {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+    }
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    // scratch rows: sc1 loads (not served from a stale L1 line: other lanes of the wavefront wrote them), plain stores
+    static __device__ __forceinline__ double ld_buf(__amdgpu_buffer_rsrc_t r, unsigned eoff, double, int aux)
+    {
+        return aux ? __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, eoff * 8u, 0, 16))
+                   : __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, eoff * 8u, 0, 0));
+    }
+    static __device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, unsigned eoff, float, int aux)
+    {
+        return aux ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, eoff * 4u, 0, 16))
+                   : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, eoff * 4u, 0, 0));
+    }
+    static __device__ __forceinline__ void st_buf(__amdgpu_buffer_rsrc_t r, unsigned eoff, double v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, v), r, eoff * 8u, 0, 0);
+    }
+    static __device__ __forceinline__ void st_buf(__amdgpu_buffer_rsrc_t r, unsigned eoff, float v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, eoff * 4u, 0, 0);
+    }
+    // "pointer" into the wavefront's scratch: an element offset; q + k, q[k] = v and ld_sc(q) read like the pointer code
+    struct SPtr {
+        const Fast2Dec *d;
+        unsigned off;
+        struct Ref {
+            const Fast2Dec *d;
+            unsigned off;
+            __device__ __forceinline__ void operator=(R v) const { st_buf(d->rs_scr, off, v); }
+        };
+        __device__ __forceinline__ SPtr operator+(int k) const { return SPtr{d, off + (unsigned)k}; }
+        __device__ __forceinline__ Ref operator[](int k) const { return Ref{d, off + (unsigned)k}; }
+    };
+    static __device__ __forceinline__ R ld_sc(SPtr q) { return ld_buf(q.d->rs_scr, q.off, R(0), 1); }
     double sigma;
 
     __device__ __forceinline__ int pa(int t) const { return (ptr >> (3 * (t - 4))) & 7; }
@@ -130,7 +173,7 @@ struct Fast2Dec {
 #endif
     __device__ __forceinline__ R chv(int e) const
     {
-        double v = (double)src[e];
+        double v = (double)ld_buf(rs_in, csrc + (unsigned)e, IN(0), 0);
         if (sigma > 0) v = llr_from_y(v, sigma);
         return (R)v;
     }
@@ -141,10 +184,10 @@ struct Fast2Dec {
         __asm__ volatile("" : "+v"(off));
         return off;
     }
-    __device__ __forceinline__ R *l8(int slot) const { return scr + fresh(C::sc_l8 + slot * 256); }
-    __device__ __forceinline__ R *l7(int slot) const { return scr + fresh(C::sc_l7 + slot * 128); }
-    __device__ __forceinline__ R *l6s(int slot) const { return scr + fresh(C::sc_l6 + slot * 64); }
-    __device__ __forceinline__ R *tls() const { return scr + fresh(C::sc_tl); }
+    __device__ __forceinline__ SPtr l8(int slot) const { return SPtr{this, fresh(cscr + (unsigned)(C::sc_l8 + slot * 256))}; }
+    __device__ __forceinline__ SPtr l7(int slot) const { return SPtr{this, fresh(cscr + (unsigned)(C::sc_l7 + slot * 128))}; }
+    __device__ __forceinline__ SPtr l6s(int slot) const { return SPtr{this, fresh(cscr + (unsigned)(C::sc_l6 + slot * 64))}; }
+    __device__ __forceinline__ SPtr tls() const { return SPtr{this, fresh(cscr + (unsigned)C::sc_tl)}; }
 
     // ---- register levels: f on own data ----
     template <int T>  // T in [2, 5]: level T from level T+1
@@ -153,7 +196,7 @@ struct Fast2Dec {
         constexpr int RO = (1 << T) / 4;
         if constexpr (T == 5 && C::L6S) {
             vm_drain();
-            const R *q = l6s(p) + pos;
+            const SPtr q = l6s(p) + pos;
 #pragma unroll
             for (int r = 0; r < RO; ++r) A[RO + r] = chk(ld_sc(q + 4 * r), ld_sc(q + 4 * r + 32));
         } else {
@@ -173,7 +216,7 @@ struct Fast2Dec {
         else w = bl0 >> (16 + pos);                              // level 4: bits 16 + e
         if constexpr (T == 5 && C::L6S) {
             vm_drain();
-            const R *q = l6s(pa(6)) + pos;
+            const SPtr q = l6s(pa(6)) + pos;
 #pragma unroll
             for (int r = 0; r < RO; ++r) A[RO + r] = g_bit<R>(ld_sc(q + 4 * r), ld_sc(q + 4 * r + 32), w, 4 * r);
         } else {
@@ -200,7 +243,7 @@ struct Fast2Dec {
     // The level-6 value of pass rr (element pos + 4 rr).  Registers: the 16 level-6 registers act as a shift
     // register -- after the 16 passes of a step the value of pass rr sits in A[16 + rr] -- so the pass loops can
     // stay rolled without a dynamically indexed register and without a round trip through memory.
-    __device__ __forceinline__ void push_l6(R v, R *o6, int e0)
+    __device__ __forceinline__ void push_l6(R v, SPtr o6, int e0)
     {
         if constexpr (C::L6S) {
             o6[e0] = v;
@@ -229,8 +272,9 @@ struct Fast2Dec {
         vm_drain();
         const uint32_t *bt = blw + pb(TOP) * NW + 16;  // beta_9: words 16..31
         const uint32_t *bh = blw + pb(HI) * NW + 8;    // beta_8: words 8..15
-        R *o8 = l8(p), *o7 = l7(p), *o6 = l6s(p);
-        const int w32 = p * 4 + pos;                   // lane index inside the codeword
+        const SPtr o8 = l8(p), o7 = l7(p), o6 = l6s(p);
+        const int w32 = (int)fresh((unsigned)(p * 4 + pos));   // lane index inside the codeword (recomputed here: the staged
+                                                               // elements' offsets are not worth a register each across the frame loop)
         const int nld = right ? 8 : 4;                 // staged elements per lane and chunk
         R *pre = A + 4;    // levels 2..5 are dead during this step (recomputed below): reuse their registers
 #pragma unroll
@@ -287,9 +331,9 @@ struct Fast2Dec {
     __device__ __forceinline__ void from_l8()
     {
         vm_drain();
-        const R *s8 = l8(pa(8));
+        const SPtr s8 = l8(pa(8));
         const uint32_t *b7 = blw + pb(7) * NW + 4;  // beta_7: words 4..7
-        R *o7 = l7(p), *o6 = l6s(p);
+        const SPtr o7 = l7(p), o6 = l6s(p);
 #ifndef POLAR_F2_CP_F64
 #define POLAR_F2_CP_F64 2
 #endif
@@ -321,10 +365,10 @@ struct Fast2Dec {
     __device__ __forceinline__ void from_l7()  // d == 6
     {
         vm_drain();
-        const R *s7 = l7(pa(7)) + pos;
+        const SPtr s7 = l7(pa(7)) + pos;
         const uint32_t *b6 = blw + pb(6) * NW + 2;  // beta_6: words 2, 3
         const uint32_t w0 = b6[0] >> pos, w1 = b6[1] >> pos;
-        R *o6 = l6s(p) + pos;
+        const SPtr o6 = l6s(p) + pos;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const R x = ld_sc(s7 + 4 * r), y = ld_sc(s7 + 4 * r + 64);
@@ -637,8 +681,8 @@ struct Fast2Dec {
         const int w32 = p * 4 + pos, j0 = 8 * P;
         vm_drain();   // the top-left level written by the root step
         {
-            const R *tl = tls();
-            R *o8 = l8(0), *o7 = l7(0);
+            const SPtr tl = tls();
+            const SPtr o8 = l8(0), o7 = l7(0);
             R v8[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -679,7 +723,7 @@ struct Fast2Dec {
             if (t >= 4) {   // node of level t that holds leaf j0: elements pos + 4r
                 const R *node = stg + ((j0 >> t) << t) + pos;
                 if (t == 6 && C::L6S) {
-                    R *o6 = l6s(p) + pos;
+                    const SPtr o6 = l6s(p) + pos;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o6[4 * r] = node[4 * r];
                 } else {
@@ -900,7 +944,8 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
     const int wave_global = blockIdx.x * C::WAVES + wave;
     const int waves_total = gridDim.x * C::WAVES;
     R *scr_wave = reinterpret_cast<R *>(P.scratch) + (size_t)wave_global * C::scratch_elems;
-    s.scr = scr_wave + (size_t)c * C::scratch_cw;
+    s.rs_scr = D::make_rsrc(scr_wave, (unsigned)(C::scratch_elems * sizeof(R)));
+    s.cscr = (unsigned)c * (unsigned)C::scratch_cw;
 
     // leading all-frozen octets (at most 15: the run must end inside the first 128-leaf subtree)
     int lead = 0;
@@ -914,9 +959,10 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
         const int frame_raw = 2 * pair + c;
         const bool live = frame_raw < P.B;
         const int frame = live ? frame_raw : P.B - 1;  // odd tail: the idle half re-decodes the last frame, no store
-        s.src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
+        s.rs_in = D::make_rsrc(reinterpret_cast<const IN *>(P.in) + (size_t)(2 * pair) * N, (unsigned)(2 * N * sizeof(IN)));
+        s.csrc = (unsigned)(frame - 2 * pair) * (unsigned)N;
         {   // root f, single path per codeword: lanes of codeword c are w = p*4 + pos = 0..31
-            R *t = s.tls();
+            const auto t = s.tls();
             const int w = p * 4 + pos;
 #pragma unroll 2
             for (int e = w; e < N / 2; e += 32) t[e] = s.chk(s.chv(e), s.chv(e + N / 2));
