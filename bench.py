@@ -101,7 +101,9 @@ def other_configs(pa, torch, device, local, snr_db):
             ("SCL_1024: N=1024 K=512 SCL L=8, 2^16 frames", lambda: pa.SCLdecode(1024, 512, L=8, device=local), 1024, 1 << 16),
             ("N=4096 K=2048 CA-SCL L=32 (LLR levels spill HBM), 2^15 frames per GPU",
              lambda: pa.CASCL(4096, 2048, L=32, device=local), 4096, 1 << 15),
-            ("SC_1024: N=1024 K=512 SC, 2^18 frames", lambda: pa.SCdecode(1024, 512, device=local), 1024, 1 << 18)):
+            ("SC_1024: N=1024 K=512 SC, 2^18 frames", lambda: pa.SCdecode(1024, 512, device=local), 1024, 1 << 18),
+            ("BP_128 (not a BASELINE config; the reference's BP_128.c): N=128 K=64 BP 100 iterations, 2^18 frames",
+             lambda: pa.BP(128, 64, iterMax=100, device=local), 128, 1 << 18)):
         try:
             d = mk()
             y = 1.0 + sigma * torch.randn(B, N, dtype=torch.float64, device=device)

@@ -2,6 +2,7 @@
 #include "polar_host.h"
 #include "bp_kernel.h"
 #include "bp_r4.h"
+#include "bp_w128.h"
 
 namespace {
 
@@ -23,10 +24,29 @@ int launch_bp_r4(polar_ctx *c, const polar::BpParams &P)
     return POLAR_OK;
 }
 
+// N = 128: one codeword per wavefront, every message in registers (bp_w128.h)
+template <typename R, typename IN>
+int launch_bp_w128(polar_ctx *c, const polar::BpParams &P)
+{
+    using Cfg = polar::BpW128Cfg<R>;
+    auto kern = polar::k_bp_w128<R, IN>;
+    const size_t lds = Cfg::lds_bytes;
+    int occ = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * Cfg::WAVES, lds));
+    if (occ < 1) occ = 1;
+    const long long blocks_needed = ((long long)P.B + Cfg::WAVES - 1) / Cfg::WAVES;
+    int grid = (int)std::min<long long>(blocks_needed, (long long)occ * c->num_cu);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * Cfg::WAVES), lds, c->stream, P);
+    HIP_TRY(c, hipGetLastError());
+    return POLAR_OK;
+}
+
 template <typename R, typename IN>
 int launch_bp(polar_ctx *c, const polar::BpParams &P)
 {
     if (P.N == 1024 && !c->force_generic) return launch_bp_r4<R, IN>(c, P);
+    if (P.N == 128 && !c->force_generic) return launch_bp_w128<R, IN>(c, P);
     auto kern = polar::k_bp<R, IN>;
     const size_t lds = polar::bp_lds_bytes<R>(P.N, P.n);
     if (lds > 160 * 1024) {   // messages do not fit a CU's LDS: rows in global scratch

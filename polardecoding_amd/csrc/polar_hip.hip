@@ -137,7 +137,7 @@ void refresh_kernel_name(polar_ctx *c)
     const char *ty = g.dtype == POLAR_F32 ? "float" : "double";
     char nm[128];
     if (g.algo == POLAR_ALGO_BP)
-        snprintf(nm, sizeof nm, (g.N == 1024 && !c->force_generic) ? "k_bp_r4<%s>" : "k_bp<%s>", ty);
+        snprintf(nm, sizeof nm, (g.N == 1024 && !c->force_generic) ? "k_bp_r4<%s>" : (g.N == 128 && !c->force_generic) ? "k_bp_w128<%s>" : "k_bp<%s>", ty);
     else
         snprintf(nm, sizeof nm, "k_scl_generic<%s,L=%d>", ty, g.L);
     if (g.algo != POLAR_ALGO_BP && g.algo != POLAR_ALGO_SC && !c->force_generic && c->n >= 9 && g.L >= 2)
