@@ -25,6 +25,9 @@ CURVES = [
     # BP: the seed-labelled log myResult_1024.zip:BP1024out_NewSEED.dat (SEED 771, 200 errors per point, iterMax 100)
     ("BP N=1024 K=512, 100 iterations (k_bp_r4)", {1.0: (200, 445), 1.5: (200, 1294), 2.0: (200, 6076), 2.5: (200, 35242), 3.0: (200, 162847), 3.5: (200, 920196)}, 1,
      ["--algo", "bp", "--N", "1024", "--K", "512", "--bp-iters", "100"], "1.0:3.5:0.5", 2000, 1 << 16),
+    # BP N=128: myResult_128.zip:BP128_BER.txt (SEED 834, 200 errors per point, iterMax 100); runs = 200 / published BLER
+    ("BP N=128 K=64, 100 iterations (k_bp_w128)", {1.0: (200, 449), 1.5: (200, 833), 2.0: (200, 1573), 2.5: (200, 3887), 3.0: (200, 12658), 3.5: (200, 37594), 4.0: (200, 98039)}, 1,
+     ["--algo", "bp", "--N", "128", "--K", "64", "--bp-iters", "100"], "1.0:4.0:0.5", 3000, 1 << 17),
 ]
 
 
