@@ -30,9 +30,13 @@ namespace polar {
 // table: three VALU instructions less per look-up, one more LDS read in the dependent chain -- 0.92 M against 1.19 M: slower).  With the messages out of LDS the table reads of form 1
 // kept the LDS pipe 68 % busy at 42 % VALU (0.90 M frames/s f64); form 3 is VALU-bound by its f64 subtractions (0.85 M).
 // Measured (2^16 frames, 50 iterations): f64 form 0 1.04 M frames/s, form 1 0.89 M; f32 form 0 1.57 M, form 1 1.81 M
-// (a float entry of the 50-cell table is half the bytes) -> -1 picks form 0 for double and form 1 for float.
+// (a float entry of the 50-cell table is half the bytes) -> -1 picks form 0 for double and form 1 for float (round 2's choice).
+// Round 3, after the L rows moved into registers (LCACHE: three codewords per CU, 39 % LDS busy): form 2, the one-round-trip
+// table form, is ahead in both types -- f64 1.206 -> 1.303 M frames/s, f32 1.81 -> 2.09 M (same box, 2^16 frames, 50
+// iterations, decisions hashed equal; profiles/r03_ab_experiments.txt run 22): five VALU instructions less per CHK than
+// form 0, and the LDS pipe now has the room for its 48 bytes per CHK.  Default: 2.
 #ifndef POLAR_BPR4_CHK
-#define POLAR_BPR4_CHK -1
+#define POLAR_BPR4_CHK 2
 #endif
 #ifndef POLAR_BPR4_ABS_LDS
 #define POLAR_BPR4_ABS_LDS 0

@@ -198,6 +198,9 @@ __device__ __forceinline__ R chk_lut1(R a, R b, const Lut<R> &L)
 template <typename R>
 __device__ __forceinline__ R chk_lut(R a, R b, const Lut<R> &L)
 {
+#ifdef POLAR_CHK_LUT_IS_LUT1   // experiment switch (tools/variant.py): the one-round-trip form wherever the compact one is used
+    return chk_lut1<R>(a, b, L);
+#endif
     const R s = a + b, d = a - b;
     const int os = L.pick(s, 0), od = L.pick(d, 16);
     const R delta = *reinterpret_cast<const R *>(reinterpret_cast<const unsigned char *>(L.dlt) + (os + od));

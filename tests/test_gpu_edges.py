@@ -118,6 +118,14 @@ def test_bench_under_torchrun_single_rank():
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["name"] == "cascl_1024_l8"
     assert d["rccl_ranks"] == 1 and len(d["devices"]) == 1 and d["devices"][0]   # what RCCL really summed over, and on what
     assert d["vs_baseline"] and d["vs_baseline"] > 1000
+    # the drop-in's real cost (SURVEY 8d "kernel-only and end-to-end"): host buffers through polar_decode_batch, PCIe both ways,
+    # and the latency of the literal per-frame replacement polar_decode(ctx, y, sigma, u_hat)
+    e = d["end_to_end"]
+    assert e["unit"] == "frames/s" and e["frames"] == 1 << 17 and 1e5 < e["value"] < d["single_launch_frames_per_s"]
+    assert e["pcie_bytes"] == (1 << 17) * (1024 * 8 + 128) and 1.0 < e["pcie_GBps"] < 70.0
+    lat = d["single_frame_latency_us"]
+    assert lat["calls"] == 1000 and 20 < lat["p10"] <= lat["median"] <= lat["p90"] < 50000
+    assert r["traffic_raw"] is None or r["traffic"] > r["traffic_raw"]   # reads corrected x 2 (only reported for the profiled batch)
 
 
 def test_two_host_threads_two_contexts(oracle):
