@@ -100,9 +100,38 @@ struct Lut {
         const int c = min(max(t, Cell<R>::BIAS - 1), Cell<R>::BIAS + 48);
         return __umul24((unsigned)c, (unsigned)STRIDE) + base;
     }
+    // select by a sign mask (all ones: a, zero: b) -- two full-rate v_bfi_b32 instead of two v_cndmask_b32 for a double
+    // (inline asm: written in C the compiler turns mask-and-merge back into v_cmp + v_cndmask)
+    static __device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b)
+    {
+        uint32_t r;
+        __asm__("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+        return r;
+    }
+    static __device__ __forceinline__ double sel_mask(uint32_t m, double a, double b)
+    {
+        const uint32_t lo = bfi(m, (uint32_t)__double2loint(a), (uint32_t)__double2loint(b));
+        const uint32_t hi = bfi(m, (uint32_t)__double2hiint(a), (uint32_t)__double2hiint(b));
+        return __hiloint2double((int)hi, (int)lo);
+    }
+    static __device__ __forceinline__ float sel_mask(uint32_t m, float a, float b)
+    {
+        return __int_as_float((int)bfi(m, (uint32_t)__float_as_int(a), (uint32_t)__float_as_int(b)));
+    }
+    static __device__ __forceinline__ uint32_t neg_mask(double t) { return (uint32_t)(__double2hiint(t) >> 31); }
+    static __device__ __forceinline__ uint32_t neg_mask(float t) { return (uint32_t)(__float_as_int(t) >> 31); }
     // T(|x|) in one LDS round trip
     __device__ __forceinline__ R tabv(R x) const
     {
+#ifdef POLAR_TABV_MASK   // measured round 3: 4.5 % SLOWER than compare + v_cndmask in the pair kernel (profiles/r03_ab_experiments.txt run 24)
+        {   // |x| - thr is negative exactly when |x| < thr (equal: +0; thr = +inf in a cell without threshold: -inf, and
+            // both T are the same there): its sign bit, spread over the word, selects T_lo; no compare, no VCC, no v_cndmask
+            const unsigned e1 = entry(x);
+            const R thr1 = *reinterpret_cast<const R *>(lds0 + e1);
+            const TP tp1 = *reinterpret_cast<const TP *>(lds0 + e1 + 32);
+            return sel_mask(neg_mask(absr(x) - thr1), tp1.lo, tp1.hi);
+        }
+#endif
 #ifdef POLAR_SENS_NOLUT   // timing sensitivity experiment only (WRONG values): no LDS traffic, same compare + select
         const unsigned e0 = entry(x);
         const R thr0 = R(1.05) + R(e0 & 1u);

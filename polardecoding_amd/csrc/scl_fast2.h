@@ -804,8 +804,14 @@ struct Fast2Dec {
     // s or -d by the partner bit at position sh of w
     static __device__ __forceinline__ R g_sel(R sum, R dif, uint32_t w, int sh)
     {
+#ifndef POLAR_F2_GSEL_MASK   // the mask / v_bfi form measured +-0 (run 24)
         const bool b = (w >> sh) & 1u;
         return b ? -dif : sum;
+#else
+        // bit -> all-ones mask (one v_bfe_i32), then v_bfi per word: no compare, no v_cndmask
+        const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)w, sh, 1);
+        return Lut<R>::sel_mask(m, -dif, sum);
+#endif
     }
     template <int K>   // leaves K (even) and K + 1 from the level-1 pair in a1 (pos 0: x, pos 1: y)
     __device__ __forceinline__ void leaf_pair(int o, uint32_t fm, R x1)
@@ -816,8 +822,13 @@ struct Fast2Dec {
         decide<K>(o, (fm >> K) & 1, q.v);
         // leaf K + 1: g0 with the bit just decided (bit 1 of bl0, set_bit_k<even>); a slot refilled by a fork took
         // bp_d / bp_td of its source and continues with bit 1, every other slot still has its own q.s / q.ts
+#ifndef POLAR_F2_GSEL_MASK
         const bool b1 = (bl0 >> 1) & 1u;
         decide_t<K + 1>(o, (fm >> (K + 1)) & 1, b1 ? -bp_d : q.s, b1 ? bp_td : q.ts);
+#else
+        const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int)bl0, 1, 1);
+        decide_t<K + 1>(o, (fm >> (K + 1)) & 1, Lut<R>::sel_mask(m1, -bp_d, q.s), Lut<R>::sel_mask(m1, bp_td, q.ts));
+#endif
     }
     __device__ __forceinline__ void octet(int o, uint32_t fm)
     {
