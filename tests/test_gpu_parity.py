@@ -323,6 +323,39 @@ def test_bp_readouts_vs_oracle_n512(oracle):
     assert np.array_equal(uh, ref_uh)
 
 
+@pytest.mark.parametrize("K,iters,B,dtype", [(64, 100, 257, "f64"), (20, 7, 5, "f64"), (100, 1, 1, "f64"), (64, 30, 131, "f32"),
+                                             (90, 2, 4, "f32")])
+def test_bp_register_kernel_n128_vs_oracle_and_lds_kernel(K, iters, B, dtype, oracle):
+    """k_bp_w128 (BP at N = 128, one codeword per wavefront, every message in registers; BP_128.c:334-388): the oracle's
+    decisions for several rates, iteration counts (1: only one left-going sweep reaches the decision) and batch sizes that
+    leave the last workgroup partly filled; the same through the observation input (2*y/std/std formed in the kernel); and
+    the generic LDS kernel k_bp (test library) on the same frames."""
+    import polardecoding_amd as pa
+    from polardecoding_amd import testing as T
+    N = 128
+    code = oracle.Code(N, K)
+    sim = oracle.Sim(4000 + K + iters)
+    sig = oracle.sigma_from_db(2.0)
+    us, ys = sim.frames(code, sig, B)
+    ys = np.stack(ys)
+    llr = np.stack([oracle.llr_from_y(y, sig) for y in ys])
+    if dtype == "f32":
+        llr = llr.astype(np.float32).astype(np.float64)
+    ref, _, _ = oracle.decode(code, llr, "BP", bp_iters=iters, dtype=dtype)
+    dec = pa.BP(N, K, iterMax=iters, dtype=pa.F64 if dtype == "f64" else pa.F32)
+    assert dec.kernel_name.startswith("k_bp_w128")
+    uh, _, _ = dec.decode_batch(llr)
+    assert np.array_equal(uh, ref)
+    if dtype == "f64":
+        uy, _, _ = dec.decode_batch_y(ys, sig)
+        assert np.array_equal(uy, ref)
+    gen = pa.BP(N, K, iterMax=iters, dtype=pa.F64 if dtype == "f64" else pa.F32)
+    T.select_kernel(gen, T.KERNEL_GENERIC)
+    assert gen.kernel_name.startswith("k_bp<")
+    ug, _, _ = gen.decode_batch(llr)
+    assert np.array_equal(ug, ref)
+
+
 @pytest.mark.parametrize("variant", ["FOUR_PER_WAVE", "AUTO", "ONE_PER_WAVE"])
 @pytest.mark.parametrize("algo,dtype,B", [("CASCL", "f64", 203), ("SCL", "f64", 64), ("CASCL", "f32", 130), ("CASCL", "f64", 1)])
 def test_tuned_list_kernels_vs_oracle(variant, algo, dtype, B, oracle):
