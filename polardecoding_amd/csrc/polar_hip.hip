@@ -176,6 +176,10 @@ void unpack_words(const uint32_t *w, int NW, int *out)
     }
 }
 
+// helper threads per direction of the host pipeline (staging of the caller's rows / unpacking of the decisions)
+#ifndef POLAR_HOST_THREADS
+#define POLAR_HOST_THREADS 4
+#endif
 int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char *frozen_mask, size_t B,
                int *u_hat, double *pm_out, unsigned *flags)
 {
@@ -241,7 +245,7 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
         const size_t f0 = k * CH, nf = std::min(CH, B - f0);
         const double *src = in + f0 * (size_t)N;
         double *dst = c->h_in[k & 1];
-        const unsigned nthr = 4;
+        const unsigned nthr = POLAR_HOST_THREADS;
         auto part = [=](unsigned t) {
             const size_t a = nf * t / nthr, b = nf * (t + 1) / nthr;
             std::memcpy(dst + a * (size_t)N, src + a * (size_t)N, (b - a) * (size_t)N * sizeof(double));
@@ -255,7 +259,7 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
     auto unpack_chunk = [&](size_t k) {   // decisions of chunk k: pinned words -> caller's int u_hat[][N]
         const size_t f0 = k * CH, nf = std::min(CH, B - f0);
         const uint32_t *hb = c->h_bits[k & 1];
-        const unsigned nthr = (unsigned)std::max<size_t>(1, std::min<size_t>(4, nf / 1024));
+        const unsigned nthr = (unsigned)std::max<size_t>(1, std::min<size_t>(POLAR_HOST_THREADS, nf / 1024));
         auto part = [=](unsigned t) {
             const size_t a = nf * t / nthr, b = nf * (t + 1) / nthr;
             for (size_t f = a; f < b; ++f) unpack_words(hb + f * NW, NW, u_hat + (f0 + f) * (size_t)N);
