@@ -109,7 +109,10 @@ __device__ __forceinline__ void wave_sync() { __asm__ volatile("s_waitcnt vmcnt(
 // loads in flight, so the kernel then runs three wavefronts per SIMD; measured on N = 4096, L = 32 (BASELINE config 5): +9 %,
 // a third less fabric read traffic; on N = 1024, L = 32 the four-wavefront kernel without it stays ahead.
 template <typename R, typename IN, int LOGL, int TLv, int TBv, int RLv = 0, int CH = 0>
-__global__ __launch_bounds__(256, RLv == 1 ? (CH ? 3 : 4) : 1) void k_scl_big(SclParams P)
+#ifndef POLAR_BIG_CH_WAVES
+#define POLAR_BIG_CH_WAVES 3
+#endif
+__global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) void k_scl_big(SclParams P)
 {
 #ifdef POLAR_STAMPS
     unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -188,7 +191,11 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? 3 : 4) : 1) void k_scl_big(Sc
             if (t >= 6) {
                 // work item = (leader q, pass k): elements e = 64k + lane of path q.  U items are loaded before the
                 // first is used, so that U round trips to L2 overlap instead of queueing behind each other.
-                constexpr int U = 4;
+#ifndef POLAR_BIG_U
+#define POLAR_BIG_U 8
+#endif
+                constexpr int U = CH ? POLAR_BIG_U : 4;   // the three-wavefront kernel has the registers for more loads in flight
+                                                          // (config 5: 8 / 8 against 4 / 4: 97.1 -> 94.5 ms; 12 or 16 spill 25+ VGPRs)
                 const int lp = t - 6, per = 1 << lp, total = nlead << lp;
                 for (int it = 0; it < total; it += U) {
                     R a[U], b[U];
@@ -220,7 +227,10 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? 3 : 4) : 1) void k_scl_big(Sc
                 // t = 4 or 5 (only when TL < 5): 64 / 2^t leaders per pass, source slots fetched by lane.  The loads of
                 // UL passes go out before the first result is needed (one round trip per UL passes instead of one per pass).
                 const int total = nlead << t;   // elements over all leaders
-                constexpr int UL = 4;
+#ifndef POLAR_BIG_UL
+#define POLAR_BIG_UL 8
+#endif
+                constexpr int UL = CH ? POLAR_BIG_UL : 4;
                 for (int it = 0; it < total; it += 64 * UL) {
                     R a[UL], b[UL];
                     uint32_t wv[UL];
@@ -277,6 +287,69 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? 3 : 4) : 1) void k_scl_big(Sc
             if (pos == 0 && p < act && leader == p) tbl[__popcll(m_lead & below)] = p;
             __asm__ volatile("" ::: "memory");
             const int LV = d - 6, K = 1 << LV;
+#ifndef POLAR_BIG_CHAIN_NO_GROUP
+            // Short chains (d = 7: two elements of level d per lane and leader; d = 8: four) would be one memory round trip per
+            // LEADER: LG leaders share a round instead, sixteen loads in flight per lane as in the long chains.
+            auto grouped = [&](auto PLc) {
+                constexpr int PL = decltype(PLc)::value;   // elements of level d per lane and leader: 2 (d = 7) or 4 (d = 8)
+                constexpr int LG = 8 / PL;                 // leaders per round: 4 or 2
+                for (int li = 0; li < nlead; li += LG) {
+                    R a[8], b[8];
+                    uint32_t wv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    R *rows_u[LG];
+#pragma unroll
+                    for (int u = 0; u < LG; ++u) {
+                        const int q = __builtin_amdgcn_readfirstlane(tbl[min(li + u, nlead - 1)]);   // past the end: the last leader again, not stored
+                        const int ss = __builtin_amdgcn_readlane(my_src, q * S);
+                        const int bs = __builtin_amdgcn_readlane(my_bits, q * S);
+                        const R *src = (d + 1 == n) ? chg : hiA + (size_t)ss * N + 2 * h;
+                        rows_u[u] = hiA + (size_t)q * N;
+                        const uint32_t *gw = gbl + (size_t)bs * NW;
+                        const uint32_t *lw = blw + bs * WL;
+#pragma unroll
+                        for (int x = 0; x < PL; ++x) {
+                            // visiting order of the elements k: 0, 1 (K = 2) or 0, 2, 1, 3 (K = 4): pairs are (k, k + K/2)
+                            const int k = (PL == 2) ? x : ((x & 1) * 2 + (x >> 1));
+                            a[u * PL + x] = ld_bypass(src + (unsigned)(64 * k + lane));
+                            b[u * PL + x] = ld_bypass(src + (unsigned)(64 * k + h + lane));
+                            if (gstep) {
+                                const int wi = (h + 64 * k + lane) >> 5;
+                                wv[u * PL + x] = (d > TB) ? ld_bypass(gw + wi) : lw[wi];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < LG; ++u) {
+                        if (li + u < nlead) {
+                            R *rows = rows_u[u];
+                            R v[PL];
+#pragma unroll
+                            for (int x = 0; x < PL; ++x) {
+                                const int k = (PL == 2) ? x : ((x & 1) * 2 + (x >> 1));
+                                v[x] = gstep ? gfun<R>(a[u * PL + x], b[u * PL + x], (wv[u * PL + x] >> (lane & 31)) & 1)
+                                             : chk_lut<R>(a[u * PL + x], b[u * PL + x], lut);
+                                rows[(unsigned)(h + 64 * k + lane)] = v[x];
+                            }
+                            if constexpr (PL == 2) {
+                                const R w = chk_lut<R>(v[0], v[1], lut);                 // level 6, element 0
+                                rows[(unsigned)(64 + lane)] = w;
+                            } else {
+                                const R w0 = chk_lut<R>(v[0], v[1], lut), w1 = chk_lut<R>(v[2], v[3], lut);   // level 7: elements 0, 1
+                                rows[(unsigned)(128 + lane)] = w0;
+                                rows[(unsigned)(128 + 64 + lane)] = w1;
+                                const R x6 = chk_lut<R>(w0, w1, lut);                    // level 6, element 0
+                                rows[(unsigned)(64 + lane)] = x6;
+                            }
+                        }
+                    }
+                }
+            };
+            if (LV == 1) {
+                grouped(std::integral_constant<int, 2>{});
+            } else if (LV == 2) {
+                grouped(std::integral_constant<int, 4>{});
+            } else
+#endif
             for (int li = 0; li < nlead; ++li) {
                 const int q = __builtin_amdgcn_readfirstlane(tbl[li]);
                 const int ss = __builtin_amdgcn_readlane(my_src, q * S);
@@ -305,15 +378,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? 3 : 4) : 1) void k_scl_big(Sc
                     rows[(unsigned)((1 << t) + 64 * k + lane)] = v;
                     return v;
                 };
-                if (LV == 1) {
-                    R a0, b0, a1, b1;
-                    uint32_t w0 = 0, w1 = 0;
-                    top_ld(0, a0, b0, w0);
-                    top_ld(1, a1, b1, w1);
-                    const R v0 = top_ev(0, a0, b0, w0), v1 = top_ev(1, a1, b1, w1);
-                    (void)fnode(6, 0, v0, v1);
-                }
-                else if (LV >= 3) {   // eight elements of level d per round: sixteen loads in flight per lane
+                if (LV >= 3) {   // eight elements of level d per round: sixteen loads in flight per lane
                     R pend3 = R(0), pend4 = R(0);
                     for (int i = 0; i < K; i += 8) {
                         const int k0 = (int)(__brev((unsigned)i) >> (32 - LV));
@@ -343,23 +408,6 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? 3 : 4) : 1) void k_scl_big(Sc
                                 }
                             }
                         }
-                    }
-                }
-                else {   // LV == 2: the four elements of level 8 in one round (same loop shape as above: K = 4, one trip)
-                    for (int i = 0; i < K; i += 4) {
-                        const int k0 = (int)(__brev((unsigned)i) >> (32 - LV));
-                        const int k1 = k0 + (K >> 1), k2 = k0 + (K >> 2), k3 = k2 + (K >> 1);
-                        R a[4], b[4];
-                        uint32_t wv[4] = {0, 0, 0, 0};
-                        top_ld(k0, a[0], b[0], wv[0]);
-                        top_ld(k1, a[1], b[1], wv[1]);
-                        top_ld(k2, a[2], b[2], wv[2]);
-                        top_ld(k3, a[3], b[3], wv[3]);
-                        const R v0 = top_ev(k0, a[0], b[0], wv[0]), v1 = top_ev(k1, a[1], b[1], wv[1]);
-                        const R w01 = fnode(d - 1, k0, v0, v1);
-                        const R v2 = top_ev(k2, a[2], b[2], wv[2]), v3 = top_ev(k3, a[3], b[3], wv[3]);
-                        const R w23 = fnode(d - 1, k2, v2, v3);
-                        (void)fnode(d - 2, k0, w01, w23);
                     }
                 }
             }
