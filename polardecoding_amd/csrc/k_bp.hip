@@ -19,7 +19,12 @@ int launch_bp_r4(polar_ctx *c, const polar::BpParams &P)
     if (occ < 1) occ = 1;
     int grid = (int)std::min<long long>((long long)P.B, (long long)occ * c->num_cu);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds, c->stream, P);
+    polar::BpParams Q = P;
+    if ((long long)P.B > (long long)grid) {
+        int rc = work_queue(c, c->scratch, &Q.queue, &Q.queue_clear);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
     return POLAR_OK;
 }
@@ -37,7 +42,12 @@ int launch_bp_w128(polar_ctx *c, const polar::BpParams &P)
     const long long blocks_needed = ((long long)P.B + Cfg::WAVES - 1) / Cfg::WAVES;
     int grid = (int)std::min<long long>(blocks_needed, (long long)occ * c->num_cu);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * Cfg::WAVES), lds, c->stream, P);
+    polar::BpParams Q = P;
+    if ((long long)P.B > (long long)grid * Cfg::WAVES) {
+        int rc = work_queue(c, c->scratch, &Q.queue, &Q.queue_clear);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * Cfg::WAVES), lds, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
     return POLAR_OK;
 }

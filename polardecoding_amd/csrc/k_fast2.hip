@@ -19,13 +19,20 @@ int launch_fast2(polar_ctx *c, const polar::SclParams &P)
     if (occ < 1) occ = 1;
     const long long pairs = ((long long)P.B + 1) / 2;
     long long blocks_needed = (pairs + WAVES - 1) / WAVES;
-    int grid = (int)std::min<long long>(blocks_needed, (long long)occ * c->num_cu);
+#ifndef POLAR_F2_GRID_MULT
+#define POLAR_F2_GRID_MULT 1
+#endif
+    int grid = (int)std::min<long long>(blocks_needed, (long long)occ * c->num_cu * POLAR_F2_GRID_MULT);
     if (grid < 1) grid = 1;
     polar::SclParams Q = P;
     const size_t sc_bytes = Cfg::scratch_elems * sizeof(R) * (size_t)grid * WAVES;
     int rc = ensure(c, c->scratch, sc_bytes);
     if (rc) return rc;
     Q.scratch = c->scratch.p;
+    if (pairs > (long long)grid * WAVES) {   // more jobs than resident wavefronts: the rest through the work queue
+        rc = work_queue(c, c->scratch, &Q.queue, &Q.queue_clear);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
     return POLAR_OK;

@@ -110,6 +110,7 @@ int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sig
     P.sc_mode = (g.algo == POLAR_ALGO_SC) ? 1 : 0;
     P.dbg = nullptr;
     P.scratch = nullptr;
+    P.queue = P.queue_clear = nullptr;
 #ifdef POLAR_STAMPS   // diagnostic builds only (tools/): per-section cycle sums, see debug_stamps.inc
 #include "debug_stamps.inc"
 #endif
@@ -455,7 +456,10 @@ void polar_destroy(polar_ctx *c)
     if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
     for (Buf *b : {&c->in, &c->bits, &c->pm, &c->flags, &c->scratch, &c->gen_llr, &c->gen_u, &c->gen_cnt, &c->in2[0],
                    &c->in2[1], &c->bits2[0], &c->bits2[1], &c->scratch_b})
+    {
         if (b->p) (void)hipFree(b->p);
+        if (b->queue) (void)hipFree(b->queue);
+    }
     for (int i = 0; i < 2; ++i) {
         if (c->h_bits[i]) (void)hipHostFree(c->h_bits[i]);
         if (c->h_in[i]) (void)hipHostFree(c->h_in[i]);

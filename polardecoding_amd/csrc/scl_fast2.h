@@ -966,7 +966,9 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
 #endif
     lead = __builtin_amdgcn_readfirstlane(lead);
 
-    for (int pair = wave_global; 2 * pair < P.B; pair += waves_total) {
+    // jobs (pairs of frames): the first one by the wavefront's index, the others from the launch's work queue
+    job_queue_begin(P);
+    for (int pair = wave_global; 2 * pair < P.B;) {
         const int frame_raw = 2 * pair + c;
         const bool live = frame_raw < P.B;
         const int frame = live ? frame_raw : P.B - 1;  // odd tail: the idle half re-decodes the last frame, no store
@@ -1071,6 +1073,7 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
         }
         lds_fence();
         STAMP(6);
+        pair = next_job_wave(P.queue, pair, waves_total);
     }
 #ifdef POLAR_STAMPS
 #ifdef POLAR_STAMPS_DECIDE   // buckets 0 / 1: time and count (x 1000) of the ranked steps, 7 / 6: of all phase-2 information leaves
