@@ -78,7 +78,12 @@ int launch_bp(polar_ctx *c, const polar::BpParams &P)
     if (occ < 1) occ = 1;
     int grid = std::min<long long>((long long)P.B, (long long)occ * c->num_cu);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, P);
+    polar::BpParams Q = P;
+    if ((long long)P.B > (long long)grid) {
+        int rc = work_queue(c, c->scratch, &Q.queue, &Q.queue_clear);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
     return POLAR_OK;
 }

@@ -891,6 +891,9 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
 #ifdef POLAR_STAMPS
     unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#ifdef POLAR_STAMPS_XCC
+    unsigned long long njobs = 0;
+#endif
 #endif
     using D = Fast2Dec<R, IN, CRC_ON>;
     using C = Fast2Cfg<R>;
@@ -1074,8 +1077,26 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
         lds_fence();
         STAMP(6);
         pair = next_job_wave(P.queue, pair, waves_total);
+#ifdef POLAR_STAMPS_XCC
+        ++njobs;
+#endif
     }
 #ifdef POLAR_STAMPS
+#ifdef POLAR_STAMPS_XCC   // diagnostic: jobs per XCD (bucket = XCC_ID) or per shader engine (POLAR_STAMPS_XCC == 2), x 1000
+    {
+        unsigned xcc, hw;
+        __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned bucket = (POLAR_STAMPS_XCC == 2) ? ((hw >> 13) & 7u) : (xcc & 7u);
+        if (POLAR_STAMPS_XCC == 3) {   // histogram of jobs per wavefront around the mean: <= mean-3, -2, -1, 0, +1, +2, +3, >= +4 (x 1000 x jobs)
+            const int mean = (P.B / 2) / waves_total;
+            bucket = (unsigned)min(max((int)njobs - mean + 3, 0), 7);
+        }
+        if (POLAR_STAMPS_XCC == 4) bucket = (hw >> 8) & 7u;    // CU_ID (low three bits)
+        if (POLAR_STAMPS_XCC == 5) bucket = (hw >> 4) & 3u;    // SIMD_ID
+        for (int i = 0; i < 8; ++i) tsec[i] = (i == (int)bucket) ? 1000ull * njobs : 0ull;
+    }
+#endif
 #ifdef POLAR_STAMPS_DECIDE   // buckets 0 / 1: time and count (x 1000) of the ranked steps, 7 / 6: of all phase-2 information leaves
     tsec[0] = s.dt_rank; tsec[1] = s.n_rank * 1000; tsec[7] += s.dt_info; tsec[6] = s.n_info * 1000;
 #endif

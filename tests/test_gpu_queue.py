@@ -1,0 +1,71 @@
+"""GPU: the work queue of the persistent kernels (csrc/polar_host.h work_queue(), csrc/polar_params.h next_job_*).
+
+A launch with more jobs than resident wavefronts hands the jobs beyond the first round out through an atomic counter; which
+wavefront decodes which frame then depends on timing.  Nothing about a frame's result may: one big launch must return,
+frame for frame, what the same frames return in launches small enough to be assigned statically (the path the oracle and
+golden-vector tests cover), again and again on the same context (the two counters of a scratch buffer alternate)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CRC24C = (0, 1, 2, 4, 8, 12, 13, 15, 17, 20, 21, 23, 24)
+CRC6 = (0, 1, 6)
+
+CASES = [
+    # algo, N, K, kwargs, frames in the big launch (ragged on purpose), frames per small launch
+    ("CASCL", 1024, 512, {"L": 8, "crc_taps": CRC24C}, 6144 * 5 + 1231, 4096),     # k_scl_fast2: 6144 frames resident
+    ("SCL", 1024, 512, {"L": 8}, 6144 * 3 + 5, 4096),
+    ("CASCL", 128, 64, {"L": 8, "crc_taps": CRC6}, 70001, 2048),                    # k_scl_fast
+    ("SCL", 1024, 512, {"L": 32}, 4096 * 2 + 333, 2048),                            # k_scl_big, four wavefronts per SIMD
+    ("CASCL", 2048, 1024, {"L": 32, "crc_taps": CRC24C}, 3072 * 2 + 77, 1024),      # k_scl_big with chain(), three per SIMD
+    ("BP", 1024, 512, {"iterMax": 10}, 768 * 4 + 19, 512),                          # k_bp_r4: one job per workgroup
+    ("BP", 128, 64, {"iterMax": 20}, 4096 * 6 + 3, 2048),                           # k_bp_w128
+    ("SC", 1024, 512, {}, (1 << 18) + 777, 16384),                                  # k_sc_lanes: jobs are batches of 64
+    ("SCL", 256, 128, {"L": 4}, 30011, 1024),                                       # k_scl_generic: one wavefront per workgroup
+    ("BP", 256, 128, {"iterMax": 10}, 9001, 512),                                   # k_bp: rows in LDS, one job per workgroup
+]
+
+
+@pytest.mark.parametrize("algo,N,K,kw,B,chunk", CASES, ids=[f"{c[0]}_{c[1]}_{'L%d' % c[3]['L'] if 'L' in c[3] else 'x'}" for c in CASES])
+def test_one_big_launch_equals_statically_assigned_small_launches(algo, N, K, kw, B, chunk):
+    import torch
+    import polardecoding_amd as pa
+    from polardecoding_amd.synth import make_batch
+    kw = dict(kw)
+    taps = kw.pop("crc_taps", None)
+    if algo == "CASCL":
+        dec = pa.CASCL(N, K, crc_taps=taps, **kw)
+    elif algo == "SCL":
+        dec = pa.SCLdecode(N, K, **kw)
+    elif algo == "BP":
+        dec = pa.BP(N, K, **kw)
+    else:
+        dec = pa.SCdecode(N, K, **kw)
+    dec.use_torch_stream()
+    info = torch.tensor(dec.info_order.astype(np.int64), device="cuda")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4242)
+    llr, _ = make_batch(B, N, K, taps, 1.5, info, "cuda", gen)   # 1.5 dB: frames differ a lot in work (ranked steps, forks)
+    lists = algo in ("CASCL", "SCL")
+
+    def run(x):
+        nb = x.shape[0]
+        bits = torch.full((nb, N // 32), -1, dtype=torch.int32, device="cuda")
+        pm = torch.full((nb,), -1.0, dtype=torch.float64, device="cuda") if lists else None
+        fl = torch.full((nb,), -1, dtype=torch.int32, device="cuda") if lists else None
+        dec.decode_device(x, out_bits=bits, pm=pm, flags=fl)
+        return bits, pm, fl
+
+    parts = [run(llr[i:i + chunk]) for i in range(0, B, chunk)]
+    ref_bits = torch.cat([p[0] for p in parts])
+    for rep in range(3):   # consecutive launches use the two counters of the scratch buffer in turn
+        bits, pm, fl = run(llr)
+        assert torch.equal(bits, ref_bits), f"decisions differ in launch {rep}"
+        assert not bool((bits == -1).all(dim=1).any()), "a frame was not decoded"   # frozen positions are 0 in u_hat
+        if lists:
+            ref_pm = torch.cat([p[1] for p in parts])
+            assert torch.equal(pm.view(torch.int64), ref_pm.view(torch.int64)), f"path metrics differ in launch {rep}"
+            assert torch.equal(fl, torch.cat([p[2] for p in parts])), f"flags differ in launch {rep}"
+        if rep == 0:
+            run(llr[:7])   # a small, statically assigned launch in between leaves the counters as the next one needs them
