@@ -179,7 +179,7 @@ void unpack_words(const uint32_t *w, int NW, int *out)
 
 // helper threads per direction of the host pipeline (staging of the caller's rows / unpacking of the decisions)
 #ifndef POLAR_HOST_THREADS
-#define POLAR_HOST_THREADS 4
+#define POLAR_HOST_THREADS 6   // 4 -> 6: end_to_end 4.4 -> 4.6-4.7 M frames/s; 8 and 12 no more (run 35)
 #endif
 int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char *frozen_mask, size_t B,
                int *u_hat, double *pm_out, unsigned *flags)
@@ -208,7 +208,10 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
     // asynchronous DMA.
     // chunk: 16384 frames, but at most 128 MiB of input (N = 1024: 16384 frames; N = 4096: 4096), so that the two pinned
     // staging buffers and the two device buffers stay at 256 MiB each whatever the block length
-    const size_t CH = std::max<size_t>(256, std::min<size_t>(16384, ((size_t)128 << 20) / ((size_t)N * sizeof(double))));
+#ifndef POLAR_HOST_CHUNK
+#define POLAR_HOST_CHUNK 16384
+#endif
+    const size_t CH = std::max<size_t>(256, std::min<size_t>(POLAR_HOST_CHUNK, ((size_t)128 << 20) / ((size_t)N * sizeof(double))));
     const size_t nch = (B + CH - 1) / CH;
     const size_t chf = std::min(B, CH);
     for (int i = 0; i < 2; ++i) {

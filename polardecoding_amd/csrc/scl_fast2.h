@@ -31,6 +31,11 @@ struct Fast2Cfg {
     static constexpr bool L6S = sizeof(R) == 8 ? (POLAR_F2_L6S_F64 != 0) : (POLAR_F2_L6S_F32 != 0);
     static constexpr int NA = L6S ? 16 : 32;   // levels 2..5 (or ..6), level t at offset 2^t/4
     static constexpr int WAVES = 4;
+// selects of the by-product g steps by sign mask + v_bfi_b32 (1) or by v_cmp + v_cndmask (0): +-0 while the wavefronts took
+// their jobs by a fixed stride (profiles/r03_ab_experiments.txt run 24), + 1.3 % since the work queue (run 34)
+#ifndef POLAR_F2_GSEL_MASK
+#define POLAR_F2_GSEL_MASK 1
+#endif
 #ifndef POLAR_F2_WAVES_F64
 #define POLAR_F2_WAVES_F64 3
 #endif
@@ -804,7 +809,7 @@ struct Fast2Dec {
     // s or -d by the partner bit at position sh of w
     static __device__ __forceinline__ R g_sel(R sum, R dif, uint32_t w, int sh)
     {
-#ifndef POLAR_F2_GSEL_MASK   // the mask / v_bfi form measured +-0 (run 24)
+#if !POLAR_F2_GSEL_MASK
         const bool b = (w >> sh) & 1u;
         return b ? -dif : sum;
 #else
@@ -822,7 +827,7 @@ struct Fast2Dec {
         decide<K>(o, (fm >> K) & 1, q.v);
         // leaf K + 1: g0 with the bit just decided (bit 1 of bl0, set_bit_k<even>); a slot refilled by a fork took
         // bp_d / bp_td of its source and continues with bit 1, every other slot still has its own q.s / q.ts
-#ifndef POLAR_F2_GSEL_MASK
+#if !POLAR_F2_GSEL_MASK
         const bool b1 = (bl0 >> 1) & 1u;
         decide_t<K + 1>(o, (fm >> (K + 1)) & 1, b1 ? -bp_d : q.s, b1 ? bp_td : q.ts);
 #else
