@@ -66,8 +66,7 @@ __global__ __launch_bounds__(512) void k_bp(BpParams P)
     __syncthreads();
 
     __shared__ int job_slot;
-    job_queue_begin(P);
-    for (int frame = blockIdx.x; frame < P.B; frame = next_job_block(P.queue, frame, (int)gridDim.x, &job_slot)) {
+    for (int frame = blockIdx.x; frame < P.B; frame = next_job_block(P.queue, frame, (int)gridDim.x, P.B, &job_slot)) {
         const IN *src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
         for (int i = tid; i < N; i += nt) {
             double v = (double)src[i];

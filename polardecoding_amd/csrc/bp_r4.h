@@ -210,8 +210,7 @@ __global__ __launch_bounds__(256, (BpR4Cfg<R>::MIN_BLOCKS)) void k_bp_r4(BpParam
     __syncthreads();
 
     __shared__ int job_slot;
-    job_queue_begin(P);
-    for (int frame = blockIdx.x; frame < P.B; frame = next_job_block(P.queue, frame, (int)gridDim.x, &job_slot)) {
+    for (int frame = blockIdx.x; frame < P.B; frame = next_job_block(P.queue, frame, (int)gridDim.x, P.B, &job_slot)) {
         const IN *src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {   // group-4 elements t + 256 k: coalesced

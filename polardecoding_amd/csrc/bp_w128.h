@@ -140,8 +140,7 @@ __global__ __launch_bounds__(256, (BpW128Cfg<R>::MIN_WAVES_PER_SIMD)) void k_bp_
     s.r0[0] = f0 ? R(999) : R(0);
     s.r0[1] = f1 ? R(999) : R(0);
 
-    job_queue_begin(P);
-    for (int frame = wg; frame < P.B; frame = next_job_wave(P.queue, frame, nw)) {
+    for (int frame = wg; frame < P.B; frame = next_job_wave(P.queue, frame, nw, P.B)) {
         const IN *src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * C::N;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {

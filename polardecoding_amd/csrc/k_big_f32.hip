@@ -24,7 +24,7 @@ int launch_big_v(polar_ctx *c, const polar::SclParams &P)
     int rc = ensure(c, c->scratch, Cfg::scratch_bytes(P.N) * (size_t)grid * Cfg::WAVES);
     if (rc) return rc;
     Q.scratch = c->scratch.p;
-    if ((long long)P.B > (long long)grid * Cfg::WAVES && (rc = work_queue(c, c->scratch, &Q.queue, &Q.queue_clear))) return rc;
+    if ((long long)P.B > (long long)grid * Cfg::WAVES && (rc = work_queue(c, c->scratch, &Q.queue))) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
     return POLAR_OK;

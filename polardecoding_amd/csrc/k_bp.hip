@@ -21,7 +21,7 @@ int launch_bp_r4(polar_ctx *c, const polar::BpParams &P)
     if (grid < 1) grid = 1;
     polar::BpParams Q = P;
     if ((long long)P.B > (long long)grid) {
-        int rc = work_queue(c, c->scratch, &Q.queue, &Q.queue_clear);
+        int rc = work_queue(c, c->scratch, &Q.queue);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), lds, c->stream, Q);
@@ -44,7 +44,7 @@ int launch_bp_w128(polar_ctx *c, const polar::BpParams &P)
     if (grid < 1) grid = 1;
     polar::BpParams Q = P;
     if ((long long)P.B > (long long)grid * Cfg::WAVES) {
-        int rc = work_queue(c, c->scratch, &Q.queue, &Q.queue_clear);
+        int rc = work_queue(c, c->scratch, &Q.queue);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * Cfg::WAVES), lds, c->stream, Q);
@@ -80,7 +80,7 @@ int launch_bp(polar_ctx *c, const polar::BpParams &P)
     if (grid < 1) grid = 1;
     polar::BpParams Q = P;
     if ((long long)P.B > (long long)grid) {
-        int rc = work_queue(c, c->scratch, &Q.queue, &Q.queue_clear);
+        int rc = work_queue(c, c->scratch, &Q.queue);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, c->stream, Q);

@@ -30,7 +30,7 @@ int launch_fast2(polar_ctx *c, const polar::SclParams &P)
     if (rc) return rc;
     Q.scratch = c->scratch.p;
     if (pairs > (long long)grid * WAVES) {   // more jobs than resident wavefronts: the rest through the work queue
-        rc = work_queue(c, c->scratch, &Q.queue, &Q.queue_clear);
+        rc = work_queue(c, c->scratch, &Q.queue);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, c->stream, Q);

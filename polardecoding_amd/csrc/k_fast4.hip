@@ -26,7 +26,7 @@ int launch_fast4(polar_ctx *c, const polar::SclParams &P)
     int rc = ensure(c, c->scratch, sc_bytes);
     if (rc) return rc;
     Q.scratch = c->scratch.p;
-    if (quads > (long long)grid * WAVES && (rc = work_queue(c, c->scratch, &Q.queue, &Q.queue_clear))) return rc;
+    if (quads > (long long)grid * WAVES && (rc = work_queue(c, c->scratch, &Q.queue))) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, c->stream, Q);
     HIP_TRY(c, hipGetLastError());
     return POLAR_OK;

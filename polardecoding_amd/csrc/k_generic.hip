@@ -26,7 +26,7 @@ int launch_scl_v(polar_ctx *c, const polar::SclParams &P)
         Q.scratch = c->scratch.p;
     }
     if ((long long)P.B > (long long)grid) {
-        int rc = work_queue(c, c->scratch, &Q.queue, &Q.queue_clear);
+        int rc = work_queue(c, c->scratch, &Q.queue);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, c->stream, Q);

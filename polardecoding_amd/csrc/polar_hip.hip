@@ -110,7 +110,7 @@ int decode_device_impl(polar_ctx *c, const void *d_in, int in_is_f32, double sig
     P.sc_mode = (g.algo == POLAR_ALGO_SC) ? 1 : 0;
     P.dbg = nullptr;
     P.scratch = nullptr;
-    P.queue = P.queue_clear = nullptr;
+    P.queue = nullptr;
 #ifdef POLAR_STAMPS   // diagnostic builds only (tools/): per-section cycle sums, see debug_stamps.inc
 #include "debug_stamps.inc"
 #endif

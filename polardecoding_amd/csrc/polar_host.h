@@ -17,8 +17,7 @@
 struct PolarBuf {
     void *p = nullptr;
     size_t cap = 0;
-    unsigned *queue = nullptr;   // work queue of the persistent kernels that use this scratch buffer (work_queue() below)
-    unsigned seq = 0;            // launches that used it
+    unsigned *queue = nullptr;   // job counter of the persistent kernels that use this scratch buffer (work_queue() below)
 };
 typedef PolarBuf Buf;
 
@@ -103,20 +102,16 @@ inline int ensure(polar_ctx *c, Buf &b, size_t bytes)
 }
 
 // Work queue of a persistent kernel.  The resident wavefronts take their first job by their index and every further one
-// from a counter (atomic add), so a wavefront on a slower CU simply takes fewer jobs: a launch ends when the work does,
-// not when the slowest statically assigned wavefront does.  Two counters per scratch buffer (the buffer and its queue
-// belong to one stream at a time): launch k counts in counter k & 1 and clears the other one for launch k + 1, which the
-// stream runs after it -- no memset between launches.
-inline int work_queue(polar_ctx *c, Buf &scratch, unsigned **counter, unsigned **clear)
+// from a counter (atomic add), so a wavefront that gets fewer issue slots simply takes fewer jobs: a launch ends when the
+// work does, not when the slowest statically assigned wavefront does.  One counter per scratch buffer
+// (the buffer and its counter belong to one stream at a time); the kernel leaves it at zero (polar_params.h job_fetch).
+inline int work_queue(polar_ctx *c, Buf &scratch, unsigned **counter)
 {
     if (!scratch.queue) {
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&scratch.queue), 256));
         HIP_TRY(c, hipMemsetAsync(scratch.queue, 0, 256, c->stream));
-        scratch.seq = 0;
     }
-    *counter = scratch.queue + (scratch.seq & 1u);
-    *clear = scratch.queue + ((scratch.seq & 1u) ^ 1u);
-    ++scratch.seq;
+    *counter = scratch.queue;
     return POLAR_OK;
 }
 

@@ -17,8 +17,7 @@ struct SclParams {
     int sc_mode;               // 1: plain SC decisions (SCdecode), L must be 1
     void *scratch;             // k_scl_fast, N = 1024: per-wave global scratch (FastCfg::scratch_elems each)
     unsigned long long *dbg;   // diagnostic builds only (-DPOLAR_STAMPS): per-section cycle sums
-    unsigned *queue;           // persistent kernels: job counter of this launch (polar_host.h work_queue()); null = static
-    unsigned *queue_clear;     //   the counter of the next launch on this stream, zeroed by this one
+    unsigned *queue;           // persistent kernels: job counter (polar_host.h work_queue()); null = jobs by a fixed stride
 };
 
 struct BpParams {
@@ -27,7 +26,7 @@ struct BpParams {
     uint32_t *out_bits;      // [B][N/32]
     const uint32_t *frozen;  // [N/32]
     int N, n, B, iters;
-    unsigned *queue, *queue_clear;   // as in SclParams
+    unsigned *queue;         // as in SclParams
 };
 
 // BP with per-stage read-outs (reference: BPr, BPr_128.c:373-575), see bp_kernel.h
@@ -46,25 +45,29 @@ struct BpReadoutParams {
 
 #ifdef __HIPCC__
 // ---- work queue of the persistent kernels (host side: polar_host.h work_queue()) ----
-// The first `resident` jobs are taken by index (wavefront or workgroup number), every further one from the launch's counter:
-// the returned job number is >= `resident`.  queue == null: static stride.
-template <typename Params>
-__device__ __forceinline__ void job_queue_begin(const Params &P)
+// The first `resident` jobs are taken by index (wavefront or workgroup number), every further one from a counter in device
+// memory: the returned job number is >= `resident`.  The counter hands out 0, 1, 2, ...; the values below total - resident
+// are jobs, and every one of the `resident` takers ends on exactly one value at or above it, so the taker that receives
+// total - 1 knows it is the last to ask and puts the counter back to zero: the next launch (or a replay of this one from
+// a captured graph) finds it as this one did, without a memset in between.  queue == null: fixed stride.
+__device__ __forceinline__ unsigned job_fetch(unsigned *queue, int total)
 {
-    if (P.queue_clear && blockIdx.x == 0 && threadIdx.x == 0) *P.queue_clear = 0u;
+    const unsigned nx = atomicAdd(queue, 1u);
+    if (nx == (unsigned)(total - 1)) atomicExch(queue, 0u);
+    return nx;
 }
-__device__ __forceinline__ int next_job_wave(unsigned *queue, int cur, int resident)
+__device__ __forceinline__ int next_job_wave(unsigned *queue, int cur, int resident, int total)
 {
     if (!queue) return cur + resident;
     unsigned nx = 0;
-    if ((threadIdx.x & 63) == 0) nx = atomicAdd(queue, 1u);
+    if ((threadIdx.x & 63) == 0) nx = job_fetch(queue, total);
     return resident + (int)__builtin_amdgcn_readfirstlane(nx);
 }
 // one job per workgroup: `slot` is one LDS word nobody else uses; every thread of the workgroup calls this
-__device__ __forceinline__ int next_job_block(unsigned *queue, int cur, int resident, int *slot)
+__device__ __forceinline__ int next_job_block(unsigned *queue, int cur, int resident, int total, int *slot)
 {
     if (!queue) return cur + resident;
-    if (threadIdx.x == 0) *slot = (int)atomicAdd(queue, 1u);
+    if (threadIdx.x == 0) *slot = (int)job_fetch(queue, total);
     __syncthreads();
     const int nx = *slot;
     __syncthreads();

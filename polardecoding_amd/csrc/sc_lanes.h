@@ -100,8 +100,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? POLAR_SC_WAVES_PER_SIMD_F32 
     auto sync = [] { __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
     const int nbatch = (P.B + 63) >> 6;
 
-    job_queue_begin(P);
-    for (int batch = slot; batch < nbatch; batch = next_job_wave(P.queue, batch, nslots)) {
+    for (int batch = slot; batch < nbatch; batch = next_job_wave(P.queue, batch, nslots, nbatch)) {
         const int frame0 = batch << 6;
         // ---- channel LLRs (SC_128.c:416-420): read in place, by the two steps at level n-1 ----
         const bool have = frame0 + lane < P.B;   // the ragged last batch: idle lanes compute on zeros and store nothing

@@ -152,8 +152,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
     uint32_t *gcur = gbl + (size_t)L * NW;
     __syncthreads();   // the tables are built; from here on the waves of a workgroup never meet again
 
-    job_queue_begin(P);
-    for (int frame = slot; frame < P.B; frame = next_job_wave(P.queue, frame, nslots)) {
+    for (int frame = slot; frame < P.B; frame = next_job_wave(P.queue, frame, nslots, P.B)) {
         {   // channel LLRs (SCL_1024.c:574-578)
             const IN *src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
             for (int i = lane; i < N; i += 64) {

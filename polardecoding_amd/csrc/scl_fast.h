@@ -770,8 +770,7 @@ __global__ __launch_bounds__(256, (FastCfg<R, NLOG>::MIN_WAVES_PER_SIMD)) void k
     const int waves_total = gridDim.x * C::WAVES;
 
     STAMP(0);
-    job_queue_begin(P);
-    for (int frame = wave_global; frame < P.B; frame = next_job_wave(P.queue, frame, waves_total)) {
+    for (int frame = wave_global; frame < P.B; frame = next_job_wave(P.queue, frame, waves_total, P.B)) {
         s.src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;
         if constexpr (C::BIG) {
             // root f, single path: the left child of the root is shared by every path (computed before any fork)

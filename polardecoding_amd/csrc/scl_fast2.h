@@ -975,7 +975,6 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
     lead = __builtin_amdgcn_readfirstlane(lead);
 
     // jobs (pairs of frames): the first one by the wavefront's index, the others from the launch's work queue
-    job_queue_begin(P);
     for (int pair = wave_global; 2 * pair < P.B;) {
         const int frame_raw = 2 * pair + c;
         const bool live = frame_raw < P.B;
@@ -1081,7 +1080,7 @@ __global__ __launch_bounds__(256, (Fast2Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
         }
         lds_fence();
         STAMP(6);
-        pair = next_job_wave(P.queue, pair, waves_total);
+        pair = next_job_wave(P.queue, pair, waves_total, (P.B + 1) >> 1);
 #ifdef POLAR_STAMPS_XCC
         ++njobs;
 #endif

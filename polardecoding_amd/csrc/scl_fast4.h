@@ -738,8 +738,7 @@ __global__ __launch_bounds__(256, (Fast4Cfg<R>::MIN_WAVES_PER_SIMD)) void k_scl_
 #endif
     lead = __builtin_amdgcn_readfirstlane(lead);
 
-    job_queue_begin(P);
-    for (int quad = wave_global; CW * quad < P.B; quad = next_job_wave(P.queue, quad, waves_total)) {
+    for (int quad = wave_global; CW * quad < P.B; quad = next_job_wave(P.queue, quad, waves_total, (P.B + CW - 1) / CW)) {
         const int frame_raw = CW * quad + c;
         const bool live = frame_raw < P.B;
         const int frame = live ? frame_raw : P.B - 1;  // ragged tail: the idle quarters re-decode the last frame, no store

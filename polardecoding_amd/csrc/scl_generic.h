@@ -82,8 +82,7 @@ __global__ __launch_bounds__(64) void k_scl_generic(SclParams P)
         else return *q;
     };
 
-    job_queue_begin(P);
-    for (int frame = blockIdx.x; frame < P.B; frame = next_job_wave(P.queue, frame, (int)gridDim.x)) {   // one wavefront per workgroup
+    for (int frame = blockIdx.x; frame < P.B; frame = next_job_wave(P.queue, frame, (int)gridDim.x, P.B)) {   // one wavefront per workgroup
         // ---- channel LLRs (SCL_1024.c:574-578) ----
         {
             const IN *src = reinterpret_cast<const IN *>(P.in) + (size_t)frame * N;

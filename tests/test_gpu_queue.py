@@ -3,7 +3,8 @@
 A launch with more jobs than resident wavefronts hands the jobs beyond the first round out through an atomic counter; which
 wavefront decodes which frame then depends on timing.  Nothing about a frame's result may: one big launch must return,
 frame for frame, what the same frames return in launches small enough to be assigned statically (the path the oracle and
-golden-vector tests cover), again and again on the same context (the two counters of a scratch buffer alternate)."""
+golden-vector tests cover), again and again on the same context: the wavefront that takes the last number puts the counter
+back to zero, so every launch -- and a replay of a captured one -- starts from the same state without a memset in between."""
 import numpy as np
 import pytest
 
@@ -59,7 +60,7 @@ def test_one_big_launch_equals_statically_assigned_small_launches(algo, N, K, kw
 
     parts = [run(llr[i:i + chunk]) for i in range(0, B, chunk)]
     ref_bits = torch.cat([p[0] for p in parts])
-    for rep in range(3):   # consecutive launches use the two counters of the scratch buffer in turn
+    for rep in range(3):   # every launch must leave the counter at zero for the next one
         bits, pm, fl = run(llr)
         assert torch.equal(bits, ref_bits), f"decisions differ in launch {rep}"
         assert not bool((bits == -1).all(dim=1).any()), "a frame was not decoded"   # frozen positions are 0 in u_hat
@@ -68,4 +69,34 @@ def test_one_big_launch_equals_statically_assigned_small_launches(algo, N, K, kw
             assert torch.equal(pm.view(torch.int64), ref_pm.view(torch.int64)), f"path metrics differ in launch {rep}"
             assert torch.equal(fl, torch.cat([p[2] for p in parts])), f"flags differ in launch {rep}"
         if rep == 0:
-            run(llr[:7])   # a small, statically assigned launch in between leaves the counters as the next one needs them
+            run(llr[:7])   # a small launch in between (fixed stride, no queue) does not touch the counter
+
+
+def test_captured_launch_can_be_replayed():
+    """A launch captured in a HIP graph carries its kernel arguments with it: the queue must be back at zero after every
+    replay without any host-side step in between (four replays of a launch of three rounds and a bit)."""
+    import torch
+    import polardecoding_amd as pa
+    from polardecoding_amd.synth import make_batch
+    dec = pa.CASCL(1024, 512, L=8, crc_taps=CRC24C)
+    info = torch.tensor(dec.info_order.astype(np.int64), device="cuda")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    B = 6144 * 3 + 11
+    llr, _ = make_batch(B, 1024, 512, CRC24C, 1.5, info, "cuda", gen)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        dec.use_torch_stream()
+        ref = dec.decode_device(llr).clone()
+        out = torch.full_like(ref, -1)
+        dec.decode_device(llr, out_bits=out)   # every allocation is done before the capture
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            dec.use_torch_stream()
+            dec.decode_device(llr, out_bits=out)
+        for rep in range(4):
+            out.fill_(-1)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), f"replay {rep}: {int((out == -1).all(dim=1).sum())} frames not decoded"
