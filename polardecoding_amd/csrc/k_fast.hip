@@ -27,7 +27,10 @@ int launch_fast(polar_ctx *c, const polar::SclParams &P)
         if (rc) return rc;
         Q.scratch = c->scratch.p;
     }
-    if ((long long)P.B > (long long)grid * WAVES) {
+    // work queue (polar_host.h): + 12 % for N = 128 in f64 (67.8 -> 76.1 M frames/s on one box); the f32 kernel at N = 128 is
+    // not short of issue slots and loses 3 % to it (89.5 -> 86.5 M): fixed stride there
+    constexpr bool QUEUE = !(sizeof(R) == 4 && NLOG == 7);
+    if (QUEUE && (long long)P.B > (long long)grid * WAVES) {
         int rc = work_queue(c, c->scratch, &Q.queue);
         if (rc) return rc;
     }
