@@ -212,7 +212,28 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
 #define POLAR_HOST_CHUNK 16384
 #endif
     const size_t CH = std::max<size_t>(256, std::min<size_t>(POLAR_HOST_CHUNK, ((size_t)128 << 20) / ((size_t)N * sizeof(double))));
-    const size_t nch = (B + CH - 1) / CH;
+    // Chunk boundaries.  Big batches ramp up and down (CH/8, CH/4, CH/2, CH ... CH, CH/2, CH/4, CH/8): nothing overlaps the
+    // staging of the first chunk nor the copy-out and unpacking of the last one, so those two are small.
+    std::vector<size_t> off{0};
+    {
+        std::vector<size_t> head, tail;
+        size_t left = B;
+        if (B >= 6 * CH && CH >= 2048) {
+            for (size_t d = 8; d >= 2; d /= 2) {
+                head.push_back(CH / d);
+                tail.insert(tail.begin(), CH / d);
+                left -= 2 * (CH / d);
+            }
+        }
+        for (size_t h : head) off.push_back(off.back() + h);
+        while (left > 0) {
+            const size_t nfc = std::min(CH, left);
+            off.push_back(off.back() + nfc);
+            left -= nfc;
+        }
+        for (size_t t : tail) off.push_back(off.back() + t);
+    }
+    const size_t nch = off.size() - 1;
     const size_t chf = std::min(B, CH);
     for (int i = 0; i < 2; ++i) {
         if ((rc = ensure(c, c->in2[i], chf * N * sizeof(double)))) return rc;
@@ -246,7 +267,7 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
         c->h_in_cap = chf * N * sizeof(double);
     }
     auto stage_chunk = [&](size_t k) {    // caller's rows of chunk k -> pinned h_in[k & 1], four threads
-        const size_t f0 = k * CH, nf = std::min(CH, B - f0);
+        const size_t f0 = off[k], nf = off[k + 1] - off[k];
         const double *src = in + f0 * (size_t)N;
         double *dst = c->h_in[k & 1];
         const unsigned nthr = POLAR_HOST_THREADS;
@@ -261,7 +282,7 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
     };
     std::thread worker;
     auto unpack_chunk = [&](size_t k) {   // decisions of chunk k: pinned words -> caller's int u_hat[][N]
-        const size_t f0 = k * CH, nf = std::min(CH, B - f0);
+        const size_t f0 = off[k], nf = off[k + 1] - off[k];
         const uint32_t *hb = c->h_bits[k & 1];
         const unsigned nthr = (unsigned)std::max<size_t>(1, std::min<size_t>(POLAR_HOST_THREADS, nf / 1024));
         auto part = [=](unsigned t) {
@@ -281,7 +302,7 @@ int host_batch(polar_ctx *c, const double *in, double sigma, const unsigned char
     };
     for (size_t k = 0; k < nch; ++k) {
         const int s = (int)(k & 1);
-        const size_t f0 = k * CH, nf = std::min(CH, B - f0);
+        const size_t f0 = off[k], nf = off[k + 1] - off[k];
         // the decode of chunk k-2 must be done with in2[s] before it is overwritten
         if (k >= 2 && hipStreamWaitEvent(c->copy_stream, c->ev_free[s], 0) != hipSuccess) return fail_join(POLAR_EDEVICE);
         const double *h_src = in + f0 * (size_t)N;

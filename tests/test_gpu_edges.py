@@ -189,13 +189,15 @@ def test_sc_channel_rows_read_in_place_any_alignment(in_dtype, shift, oracle):
     assert np.array_equal(uh, ref_uh)
 
 
-def test_host_batch_pipeline_equals_device_path():
+@pytest.mark.parametrize("chunks", [3, 7], ids=["equal_chunks", "ramped_chunks"])
+def test_host_batch_pipeline_equals_device_path(chunks):
     """polar_decode_batch on a batch of several chunks (pinned staging by helper threads, asynchronous DMA, decisions unpacked
     in the background) returns exactly what the device-pointer entry point returns on the same rows, into a caller-owned
-    output array that is reused from call to call."""
+    output array that is reused from call to call.  From six chunks on the chunk sizes ramp up and down (2048, 4096, 8192,
+    16384 ... 16384, 8192, 4096, 2048 frames), with a ragged chunk in the middle."""
     import torch
     import polardecoding_amd as pa
-    N, K, B = 128, 64, 16384 * 3 + 777
+    N, K, B = 128, 64, 16384 * chunks + 777
     rng = np.random.default_rng(4242)
     sigma = 10 ** (-1.5 / 20)
     llr = (2.0 * (1.0 + sigma * rng.standard_normal((B, N))) / sigma / sigma)
