@@ -100,3 +100,37 @@ def test_captured_launch_can_be_replayed():
             g.replay()
             torch.cuda.synchronize()
             assert torch.equal(out, ref), f"replay {rep}: {int((out == -1).all(dim=1).sum())} frames not decoded"
+
+
+@pytest.mark.parametrize("algo,kw", [("CASCL", {"L": 8, "crc_taps": CRC24C}), ("BP", {"iterMax": 50})], ids=["CASCL_1024_L8", "BP_1024_50it"])
+def test_frames_of_a_queued_launch_vs_oracle(algo, kw, oracle):
+    """the headline configurations at a batch that goes through the queue (five rounds and a ragged rest): 64 frames from
+    across the launch against the CPU oracle directly -- decisions, and for the list decoder the path metric, bit for bit"""
+    import torch
+    import polardecoding_amd as pa
+    from polardecoding_amd.synth import make_batch
+    kw = dict(kw)
+    taps = kw.pop("crc_taps", None)
+    dec = pa.CASCL(1024, 512, crc_taps=taps, **kw) if algo == "CASCL" else pa.BP(1024, 512, **kw)
+    dec.use_torch_stream()
+    info = torch.tensor(dec.info_order.astype(np.int64), device="cuda")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99)
+    B = 6144 * 5 + 1231 if algo == "CASCL" else 768 * 5 + 19
+    llr, _ = make_batch(B, 1024, 512, taps, 1.5, info, "cuda", gen)
+    pm = torch.zeros(B, dtype=torch.float64, device="cuda") if algo == "CASCL" else None
+    bits = dec.decode_device(llr, pm=pm)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(1)
+    pick = sorted(set([0, 1, B - 2, B - 1] + rng.integers(0, B, 60).tolist()))
+    code = oracle.Code(1024, 512, taps)
+    x = llr[pick].cpu().numpy()
+    if algo == "CASCL":
+        ref_uh, ref_pm, _ = oracle.decode(code, x, "CASCL", L=8)
+    else:
+        ref_uh = oracle.decode(code, x, "BP", bp_iters=50)[0]
+    w = bits[pick].cpu().numpy().view(np.uint32)
+    uh = ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(len(pick), 1024)
+    assert np.array_equal(uh, ref_uh)
+    if algo == "CASCL":
+        assert np.array_equal(pm[pick].cpu().numpy(), ref_pm)
