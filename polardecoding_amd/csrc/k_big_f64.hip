@@ -47,6 +47,13 @@ int launch_big(polar_ctx *c, const polar::SclParams &P)
 #ifndef POLAR_BIG_CH   // 0: without chain() (four wavefronts per SIMD), for same-box comparisons (tools/variant.py)
 #define POLAR_BIG_CH 1
 #endif
+                // At three wavefronts per SIMD a wavefront may use 12.9 KB of LDS: LLR level 4 moves from the registers into the
+                // LDS and level 5 from the scratch into the registers (split 4 / 7 / 1), so that nothing below level 6 is in the
+                // scratch: no leader passes, no scratch rows and no drains for levels 4 and 5 (config 5: + 2 ... 6 % depending on
+                // the box, a seventh less scratch traffic; -DPOLAR_BIG_TL3 for the 3 / 7 / 1 split)
+#ifndef POLAR_BIG_TL3
+                if (POLAR_BIG_CH && P.N >= 2048) return launch_big_v<R, IN, LOGL, 4, 7, 1, POLAR_BIG_CH>(c, P);
+#endif
                 if (POLAR_BIG_CH && P.N >= 2048) return launch_big_v<R, IN, LOGL, 3, 7, 1, POLAR_BIG_CH>(c, P);
             }
             return launch_big_v<R, IN, LOGL, 3, 7, 1>(c, P);

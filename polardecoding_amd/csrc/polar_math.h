@@ -68,6 +68,17 @@ __device__ __forceinline__ R gfun(R cU, R cL, int bit)
     return bit ? cL - cU : cL + cU;
 }
 
+// The same with the partner bit taken from bit `sh` of a word: cL - cU = cL + (-cU) exactly, so the bit only has to reach the
+// sign of cU.  (w >> sh) << 31 keeps exactly bit sh of w, and ADDING 2^31 to the high word flips the sign bit (the carry
+// leaves the word): one shift and one v_lshl_add_u32 instead of mask, compare and two selects.
+__device__ __forceinline__ double flip_bit(double x, uint32_t t) { return __hiloint2double((int)((t << 31) + (uint32_t)__double2hiint(x)), __double2loint(x)); }
+__device__ __forceinline__ float flip_bit(float x, uint32_t t) { return __int_as_float((int)((t << 31) + (uint32_t)__float_as_int(x))); }
+template <typename R>
+__device__ __forceinline__ R g_bit(R cU, R cL, uint32_t w, int sh)
+{
+    return cL + flip_bit(cU, w >> sh);
+}
+
 // channel LLR from an observation: 2*y/std/std, that order (SCL_1024.c:576), always in double
 __device__ __forceinline__ double llr_from_y(double y, double sigma) { return 2 * y / sigma / sigma; }
 

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                         const int idx = min(it + u, total - 1);
                         const int e = ((idx & (per - 1)) << 6) + lane;
                         R *out = hiA + (size_t)qs[u] * N + h;
-                        out[e] = gstep ? gfun<R>(a[u], b[u], (wv[u] >> (e & 31)) & 1) : chk_lut<R>(a[u], b[u], lut);
+                        out[e] = gstep ? g_bit<R>(a[u], b[u], wv[u], e & 31) : chk_lut<R>(a[u], b[u], lut);
                     }
                 }
             } else {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                     for (int u = 0; u < UL; ++u) {
                         const int idx = it + 64 * u + lane;
                         const int e = idx & (h - 1);
-                        const R r = gstep ? gfun<R>(a[u], b[u], (wv[u] >> e) & 1) : chk_lut<R>(a[u], b[u], lut);
+                        const R r = gstep ? g_bit<R>(a[u], b[u], wv[u], e) : chk_lut<R>(a[u], b[u], lut);
                         if (idx < total) hiA[(size_t)qq[u] * N + h + e] = r;
                     }
                 }
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
 #pragma unroll
                             for (int x = 0; x < PL; ++x) {
                                 const int k = (PL == 2) ? x : ((x & 1) * 2 + (x >> 1));
-                                v[x] = gstep ? gfun<R>(a[u * PL + x], b[u * PL + x], (wv[u * PL + x] >> (lane & 31)) & 1)
+                                v[x] = gstep ? g_bit<R>(a[u * PL + x], b[u * PL + x], wv[u * PL + x], lane & 31)
                                              : chk_lut<R>(a[u * PL + x], b[u * PL + x], lut);
                                 rows[(unsigned)(h + 64 * k + lane)] = v[x];
                             }
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                     }
                 };
                 auto top_ev = [&](int k, R a, R b, uint32_t wv) -> R {
-                    const R v = gstep ? gfun<R>(a, b, (wv >> (lane & 31)) & 1) : chk_lut<R>(a, b, lut);
+                    const R v = gstep ? g_bit<R>(a, b, wv, lane & 31) : chk_lut<R>(a, b, lut);
                     rows[(unsigned)(h + 64 * k + lane)] = v;
                     return v;
                 };
@@ -438,7 +438,10 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                         if constexpr (t == 6) w1 = blw[bs * WL + (h >> 5) + 1];
                     }
                 }
-                auto bit_of = [&](int e) -> uint32_t { return (((t == 6 && e >= 32) ? w1 : w0) >> (e & 31)) & 1u; };
+                // element e = pos + S k: bit (S k) & 31 of the word shifted down by pos (a compile-time shift per k: no per-element
+                // mask constants for the compiler to hoist out of the leaf loop and spill)
+                const uint32_t ws0 = w0 >> pos, ws1 = w1 >> pos;
+                auto gk = [&](R a, R b, int k) -> R { return g_bit<R>(a, b, (t == 6 && k * S >= 32) ? ws1 : ws0, (k * S) & 31); };
                 if constexpr (t < TR) {
                     // source level t+1 is rb, in the lanes of slot ss
                     const int sl = ss * S + pos;
@@ -449,12 +452,15 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                             a = __shfl(a, sl);
                             b = __shfl(b, sl);
                         }
-                        put(k, gstep ? gfun<R>(a, b, bit_of(pos + k * S)) : chk_lut<R>(a, b, lut));
+                        put(k, gstep ? gk(a, b, k) : chk_lut<R>(a, b, lut));
                     }
                 } else {
                     // source level t+1 is a scratch row (written by bulk, drained by its wave_sync), or the channel row
                     const R *src = (t + 1 == n) ? chg : hiA + (size_t)ss * N + 2 * h;
-                    constexpr int U = PER < 8 ? PER : 8;     // pairs of loads in flight per lane
+#ifndef POLAR_BIG_REG_U
+#define POLAR_BIG_REG_U 8
+#endif
+                    constexpr int U = PER < POLAR_BIG_REG_U ? PER : POLAR_BIG_REG_U;     // pairs of loads in flight per lane
 #pragma unroll
                     for (int k0 = 0; k0 < PER; k0 += U) {
                         R a[U], b[U];
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                         }
 #pragma unroll
                         for (int u = 0; u < U; ++u)
-                            put(k0 + u, gstep ? gfun<R>(a[u], b[u], bit_of(pos + (k0 + u) * S)) : chk_lut<R>(a[u], b[u], lut));
+                            put(k0 + u, gstep ? gk(a[u], b[u], k0 + u) : chk_lut<R>(a[u], b[u], lut));
                     }
                 }
                 ptrA = ptr_set<LOGL>(ptrA, t, p);
@@ -497,6 +503,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                 uint32_t wv = 0;
                 if constexpr (t < 5) wv = bl0 >> h;  // bit 2^t + e of the register word
                 else if (gstep) wv = blw[ptr_get<LOGL>(ptrB, 5) * WL + 1];
+                const uint32_t wvp = wv >> pos;      // element e = pos + S k <-> bit S k of wvp (a compile-time shift per k)
                 if constexpr (t == TL && RL >= 1) {
                     // level TL+1 is in the registers of slot ss: an f step follows the step that wrote the path's own row
                     // (ss == p, no exchange), a g step fetches the owner's lanes (SCL_1024.c:404-421 through the pointer)
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                             a = __shfl(a, sl);
                             b = __shfl(b, sl);
                         }
-                        out[e] = gstep ? gfun<R>(a, b, (wv >> e) & 1) : chk_lut<R>(a, b, lut);
+                        out[e] = gstep ? g_bit<R>(a, b, wvp, k * S) : chk_lut<R>(a, b, lut);
                     }
                 } else if (t == TL) {
                     const R *src = hiA + (size_t)ss * N + 2 * h;
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             const int e = e0 + u * S;
-                            out[e] = gstep ? gfun<R>(a[u], b[u], (wv >> e) & 1) : chk_lut<R>(a[u], b[u], lut);
+                            out[e] = gstep ? g_bit<R>(a[u], b[u], wv, e) : chk_lut<R>(a[u], b[u], lut);
                         }
                     }
                 } else {
@@ -538,7 +545,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                         for (int k = 0; k < PER; ++k) {
                             const int e = pos + k * S;
                             const R a = src[e], b = src[e + h];
-                            out[e] = gstep ? gfun<R>(a, b, (wv >> e) & 1) : chk_lut1<R>(a, b, lut);
+                            out[e] = gstep ? g_bit<R>(a, b, wvp, k * S) : chk_lut1<R>(a, b, lut);
                         }
                     }
                 }

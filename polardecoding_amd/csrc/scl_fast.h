@@ -130,19 +130,7 @@ __device__ __forceinline__ void lds_fence() { __asm__ volatile("" ::: "memory");
 __device__ __forceinline__ double flip(double x, uint32_t m) { return __hiloint2double(__double2hiint(x) ^ (int)m, __double2loint(x)); }
 __device__ __forceinline__ float flip(float x, uint32_t m) { return __int_as_float(__float_as_int(x) ^ (int)m); }
 // lower-node update with the partner bit at bit position `sh` of w (SCL_1024.c:412-416): cL +- cU
-// (w >> sh) << 31 keeps exactly bit sh of w, and ADDING 2^31 to the high word flips the sign bit (the carry leaves
-// the word): one shift and one v_lshl_add_u32 instead of shift, mask and xor.
-__device__ __forceinline__ double flip_bit(double x, uint32_t t) { return __hiloint2double((int)((t << 31) + (uint32_t)__double2hiint(x)), __double2loint(x)); }
-__device__ __forceinline__ float flip_bit(float x, uint32_t t) { return __int_as_float((int)((t << 31) + (uint32_t)__float_as_int(x))); }
-template <typename R>
-__device__ __forceinline__ R g_bit(R cU, R cL, uint32_t w, int sh)
-{
-#ifdef POLAR_G_OLD
-    return cL + flip(cU, (w << (31 - sh)) & 0x80000000u);
-#else
-    return cL + flip_bit(cU, w >> sh);
-#endif
-}
+// flip_bit / g_bit: polar_math.h
 
 template <typename R, int NLOG>
 struct FastCfg {

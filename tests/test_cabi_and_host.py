@@ -287,7 +287,7 @@ def test_crc_matrix_file_loader_of_the_c_abi(tmp_path):
 def test_register_budget_of_the_tuned_kernels(tmp_path):
     """Register allocation decides these kernels' speed more than any source change of round 3 did: seven spilled VGPRs in
     k_scl_big's chain() cost 8 %, thirty-seven more in k_scl_fast2 cost 9 % (4.0).  The budgets the measured
-    binaries had are pinned here (hipcc cross-compiles without a GPU): BASELINE config 5's kernel must stay at the 4 spilled VGPRs of the measured binary at three
+    binaries had are pinned here (hipcc cross-compiles without a GPU): BASELINE config 5's kernel must stay within the few spilled VGPRs of the measured binary at three
     wavefronts per SIMD, the headline kernel must stay within its three-wavefront budget with no more spills than measured."""
     import shutil
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -295,7 +295,10 @@ def test_register_budget_of_the_tuned_kernels(tmp_path):
         pytest.skip("no hipcc")
     import __graft_entry__ as g
     want = {
-        "k_big_f64": [("_ZN5polar9k_scl_bigIddLi5ELi3ELi7ELi1ELi1EEEvNS_9SclParamsE", 168, 4)],   # measured best with 4 (8 loads in flight in the level-4/5 steps); 7 in chain() lost 8 %
+        # split 4 / 7 / 1 + chain() (the shipped kernel of BASELINE config 5): measured with 2 spilled VGPRs; the same kernel with 50
+        # (per-element mask constants hoisted out of the leaf loop and reloaded one by one) lost 30 %; 7 in chain() lost 8 %
+        "k_big_f64": [("_ZN5polar9k_scl_bigIddLi5ELi4ELi7ELi1ELi1EEEvNS_9SclParamsE", 168, 4),
+                      ("_ZN5polar9k_scl_bigIddLi5ELi3ELi7ELi1ELi0EEEvNS_9SclParamsE", 128, 0)],   # N = 1024, L = 32: four wavefronts per SIMD
         "k_fast2": [("_ZN5polar11k_scl_fast2IddLb1EEEvNS_9SclParamsE", 168, 60),
                     ("_ZN5polar11k_scl_fast2IddLb0EEEvNS_9SclParamsE", 168, 60)],
     }
