@@ -30,6 +30,16 @@
 
 namespace polar {
 
+// CHK of the steps with several independent elements per lane: the one-round-trip table form in f64 (config 5 with the
+// 4 / 7 / 1 split: + 1.6 %, N = 1024 L = 32: +- 0; profiles/r03_ab_experiments.txt run 39 -- it had measured slower while
+// levels 4 and 5 still went through the scratch, run 23), the compact two-round-trip form in f32
+template <typename R>
+__device__ __forceinline__ R chk_wide(R a, R b, const Lut<R> &L)
+{
+    if constexpr (sizeof(R) == 8) return chk_lut1<R>(a, b, L);
+    else return chk_lut<R>(a, b, L);
+}
+
 __device__ __forceinline__ uint32_t ld_bypass(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <typename R, int LOGL, int TLv, int TBv, int RLv = 0>
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                         const int idx = min(it + u, total - 1);
                         const int e = ((idx & (per - 1)) << 6) + lane;
                         R *out = hiA + (size_t)qs[u] * N + h;
-                        out[e] = gstep ? g_bit<R>(a[u], b[u], wv[u], e & 31) : chk_lut<R>(a[u], b[u], lut);
+                        out[e] = gstep ? g_bit<R>(a[u], b[u], wv[u], e & 31) : chk_wide<R>(a[u], b[u], lut);
                     }
                 }
             } else {
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                     for (int u = 0; u < UL; ++u) {
                         const int idx = it + 64 * u + lane;
                         const int e = idx & (h - 1);
-                        const R r = gstep ? g_bit<R>(a[u], b[u], wv[u], e) : chk_lut<R>(a[u], b[u], lut);
+                        const R r = gstep ? g_bit<R>(a[u], b[u], wv[u], e) : chk_wide<R>(a[u], b[u], lut);
                         if (idx < total) hiA[(size_t)qq[u] * N + h + e] = r;
                     }
                 }
@@ -327,17 +337,17 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                             for (int x = 0; x < PL; ++x) {
                                 const int k = (PL == 2) ? x : ((x & 1) * 2 + (x >> 1));
                                 v[x] = gstep ? g_bit<R>(a[u * PL + x], b[u * PL + x], wv[u * PL + x], lane & 31)
-                                             : chk_lut<R>(a[u * PL + x], b[u * PL + x], lut);
+                                             : chk_wide<R>(a[u * PL + x], b[u * PL + x], lut);
                                 rows[(unsigned)(h + 64 * k + lane)] = v[x];
                             }
                             if constexpr (PL == 2) {
-                                const R w = chk_lut<R>(v[0], v[1], lut);                 // level 6, element 0
+                                const R w = chk_wide<R>(v[0], v[1], lut);                 // level 6, element 0
                                 rows[(unsigned)(64 + lane)] = w;
                             } else {
-                                const R w0 = chk_lut<R>(v[0], v[1], lut), w1 = chk_lut<R>(v[2], v[3], lut);   // level 7: elements 0, 1
+                                const R w0 = chk_wide<R>(v[0], v[1], lut), w1 = chk_wide<R>(v[2], v[3], lut);   // level 7: elements 0, 1
                                 rows[(unsigned)(128 + lane)] = w0;
                                 rows[(unsigned)(128 + 64 + lane)] = w1;
-                                const R x6 = chk_lut<R>(w0, w1, lut);                    // level 6, element 0
+                                const R x6 = chk_wide<R>(w0, w1, lut);                    // level 6, element 0
                                 rows[(unsigned)(64 + lane)] = x6;
                             }
                         }
@@ -369,12 +379,12 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                     }
                 };
                 auto top_ev = [&](int k, R a, R b, uint32_t wv) -> R {
-                    const R v = gstep ? g_bit<R>(a, b, wv, lane & 31) : chk_lut<R>(a, b, lut);
+                    const R v = gstep ? g_bit<R>(a, b, wv, lane & 31) : chk_wide<R>(a, b, lut);
                     rows[(unsigned)(h + 64 * k + lane)] = v;
                     return v;
                 };
                 auto fnode = [&](int t, int k, R x, R y) -> R {   // element k of level t from its two parents, stored
-                    const R v = chk_lut<R>(x, y, lut);
+                    const R v = chk_wide<R>(x, y, lut);
                     rows[(unsigned)((1 << t) + 64 * k + lane)] = v;
                     return v;
                 };
@@ -452,7 +462,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                             a = __shfl(a, sl);
                             b = __shfl(b, sl);
                         }
-                        put(k, gstep ? gk(a, b, k) : chk_lut<R>(a, b, lut));
+                        put(k, gstep ? gk(a, b, k) : chk_wide<R>(a, b, lut));
                     }
                 } else {
                     // source level t+1 is a scratch row (written by bulk, drained by its wave_sync), or the channel row
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                         }
 #pragma unroll
                         for (int u = 0; u < U; ++u)
-                            put(k0 + u, gstep ? gk(a[u], b[u], k0 + u) : chk_lut<R>(a[u], b[u], lut));
+                            put(k0 + u, gstep ? gk(a[u], b[u], k0 + u) : chk_wide<R>(a[u], b[u], lut));
                     }
                 }
                 ptrA = ptr_set<LOGL>(ptrA, t, p);
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
                             a = __shfl(a, sl);
                             b = __shfl(b, sl);
                         }
-                        out[e] = gstep ? g_bit<R>(a, b, wvp, k * S) : chk_lut<R>(a, b, lut);
+                        out[e] = gstep ? g_bit<R>(a, b, wvp, k * S) : chk_wide<R>(a, b, lut);
                     }
                 } else if (t == TL) {
                     const R *src = hiA + (size_t)ss * N + 2 * h;
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(256, RLv == 1 ? (CH ? POLAR_BIG_CH_WAVES : 4) : 1) 
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             const int e = e0 + u * S;
-                            out[e] = gstep ? g_bit<R>(a[u], b[u], wv, e) : chk_lut<R>(a[u], b[u], lut);
+                            out[e] = gstep ? g_bit<R>(a[u], b[u], wv, e) : chk_wide<R>(a[u], b[u], lut);
                         }
                     }
                 } else {
