@@ -35,6 +35,12 @@ template <typename R, typename IN, int LOGL>
 int launch_big(polar_ctx *c, const polar::SclParams &P)
 {
     const int use = c->big_split ? c->big_split : (sizeof(R) == 8 ? (LOGL == 5 ? 371 : 35) : 46);
+    // long codes, L = 32: the structure of the f64 kernel of BASELINE config 5 (chain() of the upper levels, split 4 / 7 / 1,
+    // three wavefronts per SIMD: k_big_f64.hip) -- f32, N = 4096: 0.391 -> 0.453 M frames/s, same decisions as the 4 / 6 kernel
+    // on the whole 2^15-frame batch (four wavefronts per SIMD spill 16 VGPRs: 0.427 M)
+    if constexpr (LOGL == 5) {
+        if (!c->big_split && P.N >= 2048) return launch_big_v<R, IN, LOGL, 4, 7, 1, 1>(c, P);
+    }
     if constexpr (LOGL == 5) {   // L = 32: LLR level TL+1 in registers (third digit of the split code; two such levels, and
                                  // one above four LDS levels, measured slower: fewer resident wavefronts).  At the four
                                  // wavefronts per SIMD of that kernel the LDS has room for partial-sum levels 6 and 7 too

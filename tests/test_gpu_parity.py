@@ -110,6 +110,23 @@ def test_config5_spilled_levels_vs_oracle(N, K, L, crc, oracle):
     assert np.array_equal(pm, ref_pm)
 
 
+def test_config5_f32_kernel_vs_f32_oracle(oracle):
+    """the f32 instantiation of the config-5 kernel (chain(), split 4 / 7 / 1, three wavefronts per SIMD) keeps the operation
+    order: bit-identical to the oracle's f32 instantiation (decisions; the path metric as float)"""
+    import polardecoding_amd as pa
+    N, K, L = 4096, 2048, 32
+    dec = pa.CASCL(N, K, L=L, crc_taps=pa.CRC24C_TAPS, dtype=pa.F32)
+    code = _oracle_code_like(oracle, dec, N, K, pa.CRC24C_TAPS)
+    sim = oracle.Sim(977)
+    sig = oracle.sigma_from_db(1.5)
+    us, ys = sim.frames(code, sig, 6)
+    llr = np.stack([oracle.llr_from_y(y, sig) for y in ys]).astype(np.float32).astype(np.float64)
+    ref_uh, ref_pm, _ = oracle.decode(code, llr, "CASCL", L=L, dtype="f32")
+    uh, pm, fl = dec.decode_batch(llr)
+    assert np.array_equal(uh, ref_uh)
+    assert np.array_equal(np.asarray(pm, dtype=np.float32), np.asarray(ref_pm, dtype=np.float32))
+
+
 def test_forced_spill_matches_golden():
     """The global-scratch variant on a shape that also fits LDS: same bits as the reference."""
     import polardecoding_amd as pa
