@@ -2,6 +2,10 @@
 #include "polar_host.h"
 #include "scl_big.h"
 
+#ifndef POLAR_BIG_CH_MINN
+#define POLAR_BIG_CH_MINN 2048   // shortest code that runs the chain() kernel (N = 1024: see DESIGN.md 4.2)
+#endif
+
 namespace {
 
 // big lists / long codes: low LLR levels in LDS, the rest in a per-wave scratch slice (scl_big.h)
@@ -39,7 +43,7 @@ int launch_big(polar_ctx *c, const polar::SclParams &P)
     // three wavefronts per SIMD: k_big_f64.hip) -- f32, N = 4096: 0.391 -> 0.453 M frames/s, same decisions as the 4 / 6 kernel
     // on the whole 2^15-frame batch (four wavefronts per SIMD spill 16 VGPRs: 0.427 M)
     if constexpr (LOGL == 5) {
-        if (!c->big_split && P.N >= 2048) return launch_big_v<R, IN, LOGL, 4, 7, 1, 1>(c, P);
+        if (!c->big_split && P.N >= POLAR_BIG_CH_MINN) return launch_big_v<R, IN, LOGL, 4, 7, 1, 1>(c, P);
     }
     if constexpr (LOGL == 5) {   // L = 32: LLR level TL+1 in registers (third digit of the split code; two such levels, and
                                  // one above four LDS levels, measured slower: fewer resident wavefronts).  At the four
@@ -50,7 +54,7 @@ int launch_big(polar_ctx *c, const polar::SclParams &P)
             // long codes in f64 (BASELINE config 5, N = 4096): the f chains of the upper levels in one pass, three
             // wavefronts per SIMD (scl_big.h, chain()); N = 1024 keeps the four-wavefront kernel
             if constexpr (sizeof(R) == 8) {
-                if (P.N >= 2048) return launch_big_v<R, IN, LOGL, 3, 7, 1, 1>(c, P);
+                if (P.N >= POLAR_BIG_CH_MINN) return launch_big_v<R, IN, LOGL, 3, 7, 1, 1>(c, P);
             }
             return launch_big_v<R, IN, LOGL, 3, 7, 1>(c, P);
         }

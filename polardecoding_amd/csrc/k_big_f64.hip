@@ -2,6 +2,10 @@
 #include "polar_host.h"
 #include "scl_big.h"
 
+#ifndef POLAR_BIG_CH_MINN
+#define POLAR_BIG_CH_MINN 1024   // shortest code that runs the chain() kernel (N = 1024, L = 32: 1.549 -> 1.586 M frames/s since the 4 / 7 / 1 split)
+#endif
+
 namespace {
 
 // big lists / long codes: low LLR levels in LDS, the rest in a per-wave scratch slice (scl_big.h)
@@ -41,8 +45,8 @@ int launch_big(polar_ctx *c, const polar::SclParams &P)
                                  // (371: two scratch round trips less per 128 leaves, +3 %)
         if (use == 351) return launch_big_v<R, IN, LOGL, 3, 5, 1>(c, P);
         if (use == 371) {
-            // long codes in f64 (BASELINE config 5, N = 4096): the f chains of the upper levels in one pass, three
-            // wavefronts per SIMD (scl_big.h, chain()); N = 1024 keeps the four-wavefront kernel
+            // f64, N >= 1024 (BASELINE config 5: N = 4096): the f chains of the upper levels in one pass, three wavefronts per
+            // SIMD (scl_big.h, chain())
             if constexpr (sizeof(R) == 8) {
 #ifndef POLAR_BIG_CH   // 0: without chain() (four wavefronts per SIMD), for same-box comparisons (tools/variant.py)
 #define POLAR_BIG_CH 1
@@ -52,9 +56,9 @@ int launch_big(polar_ctx *c, const polar::SclParams &P)
                 // scratch: no leader passes, no scratch rows and no drains for levels 4 and 5 (config 5: + 2 ... 6 % depending on
                 // the box, a seventh less scratch traffic; -DPOLAR_BIG_TL3 for the 3 / 7 / 1 split)
 #ifndef POLAR_BIG_TL3
-                if (POLAR_BIG_CH && P.N >= 2048) return launch_big_v<R, IN, LOGL, 4, 7, 1, POLAR_BIG_CH>(c, P);
+                if (POLAR_BIG_CH && P.N >= POLAR_BIG_CH_MINN) return launch_big_v<R, IN, LOGL, 4, 7, 1, POLAR_BIG_CH>(c, P);
 #endif
-                if (POLAR_BIG_CH && P.N >= 2048) return launch_big_v<R, IN, LOGL, 3, 7, 1, POLAR_BIG_CH>(c, P);
+                if (POLAR_BIG_CH && P.N >= POLAR_BIG_CH_MINN) return launch_big_v<R, IN, LOGL, 3, 7, 1, POLAR_BIG_CH>(c, P);
             }
             return launch_big_v<R, IN, LOGL, 3, 7, 1>(c, P);
         }
