@@ -37,6 +37,11 @@ for d in decs:
 db = (res[0][0] != res[1][0]).any(dim=1); dp = res[0][1].view(torch.int64) != res[1][1].view(torch.int64); df = res[0][2] != res[1][2]
 bad = torch.nonzero(db | dp | df).flatten().tolist()
 print(f"{len(bad)} of {B} frames differ: bits {int(db.sum())}, pm {int(dp.sum())}, flags {int(df.sum())}")
+bb = torch.nonzero(db).flatten().tolist()
+print("first frames with different decisions:", bb[:24])
+print("  of them below 3072 (first job of a wavefront):", sum(1 for f in bb if f < 3072), " below 6144:", sum(1 for f in bb if f < 6144))
+fx = (res[0][2] ^ res[1][2])
+print("flag bits that differ (bit: frames):", {b: int(((fx >> b) & 1).sum()) for b in range(4)})
 if bad:
     from oracle import oracle_py as O
     io = decs[0].info_order
